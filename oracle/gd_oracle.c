@@ -1,0 +1,1245 @@
+/*
+ * ORACLE -- test infrastructure, NOT product code.
+ *
+ * A plain-C, CPU restatement of the GPUDrive per-world step (reference CPU ExecMode
+ * semantics).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product path (gpudrive_lab_amd/csrc) never links or calls it.
+ *
+ * Parity status: the reference itself cannot be built here (external/madrona and
+ * external/json are empty submodules), so this restatement is pinned only by the
+ * reference's own known-answer tests (tests/test_oracle_pins.py re-states them):
+ *   tests/CollisionDetectionTests.cpp:11-85, tests/EgocentricRoadObservationTests.cpp:9-22,
+ *   tests/bicyclemodel.cpp:84-100,187-242, tests/observationTest.cpp:87-139,
+ *   tests/test_delta_model.py, tests/test_waymax_model.py, tests/test_expert.py.
+ * k-NN selection order, partner observations, reward/done sequencing and BEV have no
+ * reference test: for those rows PARITY IS UNPINNED (line-by-line restatement only).
+ *
+ * Third-party arithmetic that lives in the absent submodule shacklettbp/madrona
+ * (pinned commit unknown) is restated from its published definitions:
+ *   Quat{w,x,y,z}; angleAxis(a, n) = {cosf(a/2), n*sinf(a/2)}; inv = conjugate;
+ *   Hamilton product; rotateVec(v) = v + 2*((p x v)*w + p x (p x v));
+ *   Vector::length = sqrtf(x*x + y*y (+ z*z)); vector /= s multiplies by 1.f/s.
+ *
+ * Paths below are relative to /root/reference.
+ * Build: see oracle/Makefile (-ffp-contract=off: the reference's x86-64 build has no FMA).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define K_MAP 200            /* src/consts.hpp:13 kMaxAgentMapObservationsCount */
+#define MAX_ROADS_ENT 10000  /* src/consts.hpp:12 kMaxRoadEntityCount */
+#define EPISODE_LEN 91       /* src/consts.hpp:34 */
+#define TRAJ_LEN 91          /* src/consts.hpp:59 */
+#define TRAJ_F (16 * TRAJ_LEN) /* src/types.hpp:373 */
+#define BEV_RES 200          /* src/consts.hpp:49 */
+#define LIDAR_N 50
+#define MAXA 128
+
+static const float PI_F = 3.14159265358979323846f; /* madrona::math::pi */
+#define PI_M2 (PI_F * 2.f)
+static const float PAD_X = -11000.f, PAD_Y = -11000.f, PAD_Z = FLT_MAX; /* consts.hpp:64 */
+
+enum { ET_NONE = 0, ET_ROADEDGE, ET_ROADLINE, ET_ROADLANE, ET_CROSSWALK, ET_SPEEDBUMP,
+       ET_STOPSIGN, ET_VEHICLE, ET_PEDESTRIAN, ET_CYCLIST, ET_PADDING };
+enum { RESP_DYNAMIC = 0, RESP_KINEMATIC = 1, RESP_STATIC = 2 };
+enum { REW_DISTANCE = 0, REW_ONGOAL = 1, REW_DENSE = 2 };
+enum { COL_STOP = 0, COL_REMOVED = 1, COL_IGNORE = 2 };
+enum { DYN_CLASSIC = 0, DYN_BICYCLE = 1, DYN_DELTA = 2, DYN_STATE = 3 };
+enum { ROADS_KNN = 0, ROADS_LINEAR = 1 };
+
+/* src/init.hpp:111-127 */
+typedef struct {
+    float polylineReductionThreshold;
+    float observationRadius;
+    int32_t rewardType;
+    float distanceToGoalThreshold;
+    float distanceToExpertThreshold;
+    int32_t collisionBehaviour;
+    uint32_t maxNumControlledAgents;
+    int32_t IgnoreNonVehicles;
+    int32_t roadObservationAlgorithm;
+    int32_t initOnlyValidAgentsAtFirstStep;
+    int32_t isStaticAgentControlled;
+    int32_t enableLidar;
+    int32_t disableClassicalObs;
+    int32_t dynamicsModel;
+    int32_t readFromTracksToPredict;
+    int32_t enableBev; /* oracle switch: BEV is 160 KB/agent */
+} orc_params;
+
+/* packed Map (oracle/scene.py pack_map) */
+typedef struct {
+    int32_t n_obj;
+    const float *obj_pos;    /* [n_obj][91][2] */
+    const float *obj_vel;    /* [n_obj][91][2] */
+    const float *obj_head;   /* [n_obj][91] */
+    const int32_t *obj_valid;/* [n_obj][91] */
+    const int32_t *obj_npos; /* [n_obj] */
+    const float *obj_size;   /* [n_obj][3] length,width,height */
+    const float *obj_goal;   /* [n_obj][2] */
+    const int32_t *obj_type, *obj_id, *obj_expert;
+    const int32_t *obj_meta; /* [n_obj][4] */
+    int32_t n_road;
+    const int32_t *road_off; /* [n_road+1] */
+    const float *road_pts;   /* [npts][2] */
+    const int32_t *road_type, *road_id, *road_maptype;
+    float mean[2];
+    char name[32];
+    char scenario_id[32];
+} orc_map;
+
+typedef struct { float w, x, y, z; } Quat;
+typedef struct { float x, y, z; } V3;
+typedef struct { float x, y; } V2;
+
+/* ---- madrona math (restated, see header) ---- */
+static inline Quat q_angle_axis_up(float a) {
+    float c = cosf(a / 2.f), s = sinf(a / 2.f);
+    Quat q = { c, 0.f * s, 0.f * s, 1.f * s };
+    return q;
+}
+static inline Quat q_inv(Quat q) { Quat r = { q.w, -q.x, -q.y, -q.z }; return r; }
+static inline Quat q_mul(Quat a, Quat o) {
+    Quat r = {
+        (a.w * o.w - a.x * o.x - a.y * o.y - a.z * o.z),
+        (a.w * o.x + a.x * o.w + a.y * o.z - a.z * o.y),
+        (a.w * o.y - a.x * o.z + a.y * o.w + a.z * o.x),
+        (a.w * o.z + a.x * o.y - a.y * o.x + a.z * o.w),
+    };
+    return r;
+}
+static inline V3 v3_cross(V3 a, V3 b) {
+    V3 r = { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+    return r;
+}
+static inline V3 q_rotate(Quat q, V3 v) {
+    V3 pure = { q.x, q.y, q.z };
+    float scalar = q.w;
+    V3 pxv = v3_cross(pure, v);
+    V3 pxpxv = v3_cross(pure, pxv);
+    V3 r = { v.x + 2.f * ((pxv.x * scalar) + pxpxv.x),
+             v.y + 2.f * ((pxv.y * scalar) + pxpxv.y),
+             v.z + 2.f * ((pxv.z * scalar) + pxpxv.z) };
+    return r;
+}
+static inline float v2_len2(float x, float y) { return x * x + y * y; }
+static inline float v2_len(float x, float y) { return sqrtf(x * x + y * y); }
+static inline float v3_len(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+
+/* src/utils.hpp:11-25 */
+static inline float normalize_angle(float angle) {
+    const float ret = fmodf(angle, PI_M2);
+    return ret > PI_F ? ret - PI_M2 : (ret < -PI_F ? ret + PI_M2 : ret);
+}
+static inline float angle_add(float a, float b) { return normalize_angle(a + b); }
+static inline float quat_to_yaw(Quat q) {
+    return atan2f(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
+}
+
+/* src/types.hpp:210-230 MapObservation (9 floats) */
+typedef struct { float x, y, d0, d1, d2, heading, type, id, mapType; } MapObs;
+static inline MapObs mapobs_zero(void) { /* types.hpp:219-229 */
+    MapObs m = { 0, 0, 0, 0, 0, 0, (float)ET_NONE, -1.f, -1.f };
+    return m;
+}
+
+/* src/utils.hpp:27-65 ReferenceFrame */
+typedef struct { V2 pos; Quat rot; } RefFrame;
+static inline V2 rf_relative_pos(const RefFrame *rf, V3 abs) {
+    V3 rel = { abs.x - rf->pos.x, abs.y - rf->pos.y, 0 };
+    V3 r = q_rotate(q_inv(rf->rot), rel);
+    V2 o = { r.x, r.y };
+    return o;
+}
+static inline float rf_relative_rot(const RefFrame *rf, Quat abs) {
+    return quat_to_yaw(q_mul(q_inv(rf->rot), abs));
+}
+static inline MapObs rf_observation_of(const RefFrame *rf, V3 pos, Quat rot, const float scale[3],
+                                       int type, float id, int mapType) {
+    V2 p = rf_relative_pos(rf, pos);
+    MapObs m = { p.x, p.y, scale[0], scale[1], scale[2], rf_relative_rot(rf, rot),
+                 (float)type, id, (float)mapType };
+    return m;
+}
+static inline float rf_distance_to(const RefFrame *rf, V3 pos) {
+    V2 p = rf_relative_pos(rf, pos);
+    return v2_len(p.x, p.y);
+}
+
+/* ---- per-world state ---- */
+typedef struct {
+    V3 pos; Quat rot; float scale[3]; int type; int id; int mapType;
+} RoadEnt;
+
+typedef struct {
+    /* Agent archetype (src/types.hpp:480-511) */
+    V3 pos; Quat rot; float scale[3];
+    V3 vel_lin; V3 vel_ang;
+    int resp;            /* ResponseType on the Agent entity */
+    int collided;        /* CollisionDetectionEvent */
+    int etype;
+    float size[3];       /* VehicleSize length,width,height */
+    V2 goal;
+} AgentEnt;
+
+typedef struct {
+    orc_map map;         /* deep copy */
+    int has_map;
+    int reset_flag;      /* WorldReset */
+    int reset_map;       /* ResetMap */
+    int num_agents, num_roads, num_controlled;
+    AgentEnt agents[MAXA];
+    RoadEnt *roads;      /* [MAX_ROADS_ENT] */
+} World;
+
+typedef struct {
+    orc_params p;
+    int W, A;
+    World *worlds;
+    /* exported tensors, contiguous [W][A][...] (src/mgr.cpp:656-902) */
+    float *action;       /* [W][A][10] */
+    float *reward;       /* [W][A][1] */
+    int32_t *done;       /* [W][A][1] */
+    int32_t *info;       /* [W][A][5] */
+    float *self_obs;     /* [W][A][8] */
+    float *abs_obs;      /* [W][A][14] */
+    float *partner_obs;  /* [W][A][A-1][9] */
+    float *agent_map_obs;/* [W][A][200][9] */
+    float *map_obs;      /* [W][10000][9] */
+    float *lidar;        /* [W][A][3][50][4] */
+    float *bev;          /* [W][A][200][200] or NULL */
+    uint32_t *steps_remaining; /* [W][A][1] */
+    int32_t *shape;      /* [W][2] */
+    int32_t *controlled; /* [W][A][1] */
+    int32_t *resp_type;  /* [W][A][1] */
+    float *trajectory;   /* [W][A][1456] */
+    float *world_means;  /* [W][3] */
+    int32_t *metadata;   /* [W][A][4] */
+    int32_t *deleted;    /* [W][A] */
+    int32_t *map_name;   /* [W][32] */
+    int32_t *scenario_id;/* [W][32] */
+    int32_t *agent_id;   /* [W][A] (AgentID component, not exported by the reference) */
+    /* instrumentation (not part of the reference): heap inserts per agent in k-NN */
+    int64_t knn_inserts;
+} orc_sim;
+
+enum { T_ACTION = 0, T_REWARD, T_DONE, T_INFO, T_SELF, T_ABS, T_PARTNER, T_AGENT_MAP, T_MAP,
+       T_LIDAR, T_BEV, T_STEPS, T_SHAPE, T_CONTROLLED, T_RESP, T_TRAJ, T_MEANS, T_META,
+       T_DELETED, T_MAPNAME, T_SCENARIO, T_AGENT_ID, T_NUM };
+
+#define IDX_WA(s, w, a) ((size_t)(w) * (s)->A + (a))
+
+/* trajectory accessors (src/types.hpp:348-371): pos[91][2] vel[91][2] head[91] valid[91] inv[91][10] */
+static inline float *traj_of(orc_sim *s, int w, int a) { return s->trajectory + IDX_WA(s, w, a) * TRAJ_F; }
+#define TR_POS(t, i, c)  ((t)[(i) * 2 + (c)])
+#define TR_VEL(t, i, c)  ((t)[2 * TRAJ_LEN + (i) * 2 + (c)])
+#define TR_HEAD(t, i)    ((t)[4 * TRAJ_LEN + (i)])
+#define TR_VALID(t, i)   ((t)[5 * TRAJ_LEN + (i)])
+#define TR_INV(t, i)     ((t) + 6 * TRAJ_LEN + (i) * 10)
+
+/* ------------------------------------------------------------------ */
+/* dynamics (src/dynamics.hpp)                                         */
+/* ------------------------------------------------------------------ */
+
+/* src/dynamics.hpp:11-50 */
+static void forward_kinematics(const float *action, const float *size, Quat *rotation, V3 *position,
+                               V3 *vlin, V3 *vang) {
+    const float maxSpeed = FLT_MAX;
+    const float dt = 0.1f;
+    float speed = v3_len(vlin->x, vlin->y, vlin->z);
+    float yaw = quat_to_yaw(*rotation);
+    float v = fmaxf(fminf(speed + 0.5f * action[0] * dt, maxSpeed), -maxSpeed);
+    const float tanDelta = tanf(action[1]);
+    const float beta = atanf(0.5f * tanDelta);
+    const float dxv = v * cosf(yaw + beta), dyv = v * sinf(yaw + beta);
+    const float w = v * cosf(beta) * tanDelta / size[0];
+    float new_yaw = angle_add(yaw, w * dt);
+    float new_speed = fmaxf(fminf(speed + action[0] * dt, maxSpeed), -maxSpeed);
+    position->x += dxv * dt;
+    position->y += dyv * dt;
+    position->z = 1;
+    *rotation = q_angle_axis_up(new_yaw);
+    vlin->x = new_speed * cosf(new_yaw);
+    vlin->y = new_speed * sinf(new_yaw);
+    vlin->z = 0;
+    vang->x = 0; vang->y = 0; vang->z = w;
+}
+
+/* src/dynamics.hpp:52-81 (clamps are written back into the action buffer) */
+static void forward_bicycle(float *action, Quat *rotation, V3 *position, V3 *vlin, V3 *vang) {
+    action[0] = fmaxf(-6.0f, fminf(action[0], 6.0f));
+    action[1] = fmaxf(-3.0f, fminf(action[1], 3.0f));
+    const float dt = 0.1f;
+    float yaw = quat_to_yaw(*rotation);
+    float speed = v3_len(vlin->x, vlin->y, vlin->z);
+    /* float + float*float, then + double expression */
+    position->x = (float)((double)(position->x + vlin->x * dt) + 0.5 * action[0] * cosf(yaw) * dt * dt);
+    position->y = (float)((double)(position->y + vlin->y * dt) + 0.5 * action[0] * sinf(yaw) * dt * dt);
+    float delta_yaw = (float)(action[1] * ((double)(speed * dt) + 0.5 * action[0] * dt * dt));
+    float new_yaw = angle_add(yaw, delta_yaw);
+    float new_speed = speed + action[0] * dt;
+    vlin->x = new_speed * cosf(new_yaw);
+    vlin->y = new_speed * sinf(new_yaw);
+    vlin->z = 0;
+    vang->x = 0; vang->y = 0; vang->z = delta_yaw / dt;
+    *rotation = q_angle_axis_up(new_yaw);
+}
+
+/* src/dynamics.hpp:83-115 */
+static void forward_delta(const float *action, Quat *rotation, V3 *position, V3 *vlin, V3 *vang) {
+    const float dt = 0.1f;
+    float yaw = quat_to_yaw(*rotation);
+    float c = cosf(yaw), sn = sinf(yaw);
+    float dx = action[0] * c - action[1] * sn;
+    float dy = action[0] * sn + action[1] * c;
+    position->x = position->x + dx;
+    position->y = position->y + dy;
+    vlin->x = dx / dt;
+    vlin->y = dy / dt;
+    vlin->z = 0;
+    vang->x = 0; vang->y = 0; vang->z = action[2] / dt;
+    float new_yaw = angle_add(yaw, action[2]);
+    *rotation = q_angle_axis_up(new_yaw);
+}
+
+/* src/dynamics.hpp:186-194; StateAction = pos(3) yaw(1) vel lin(3) ang(3) (types.hpp:129-134) */
+static void forward_state(const float *action, Quat *rotation, V3 *position, V3 *vlin, V3 *vang) {
+    position->x = action[0]; position->y = action[1]; position->z = action[2];
+    vlin->x = action[4]; vlin->y = action[5]; vlin->z = action[6];
+    vang->x = action[7]; vang->y = action[8]; vang->z = action[9];
+    *rotation = q_angle_axis_up(action[3]);
+}
+
+/* src/dynamics.hpp:117-150 */
+static void inverse_bicycle(Quat rotation, V3 vlin, Quat targetRotation, V3 tvlin, float *out) {
+    const float dt = 0.1f;
+    memset(out, 0, 10 * sizeof(float));
+    float speed = v3_len(vlin.x, vlin.y, vlin.z);
+    float target_speed = v3_len(tvlin.x, tvlin.y, tvlin.z);
+    out[0] = (target_speed - speed) / dt;
+    float yaw = normalize_angle(quat_to_yaw(rotation));
+    float target_yaw = normalize_angle(quat_to_yaw(targetRotation));
+    /* consts::useEstimatedYaw == true */
+    target_yaw = atan2f(tvlin.y, tvlin.x);
+    float denominator = (float)((double)(speed * dt) + 0.5 * out[0] * dt * dt);
+    if (denominator != 0) out[1] = (target_yaw - yaw) / denominator;
+    else out[1] = 0;
+}
+
+/* src/dynamics.hpp:152-184 */
+static void inverse_delta(Quat rotation, V3 position, Quat targetRotation, V3 targetPosition, float *out) {
+    memset(out, 0, 10 * sizeof(float));
+    float yaw = quat_to_yaw(rotation);
+    float target_yaw = quat_to_yaw(targetRotation);
+    float dx = targetPosition.x - position.x;
+    float dy = targetPosition.y - position.y;
+    float dyaw = target_yaw - yaw;
+    dx = fmaxf(-6.0f, fminf(dx, 6.0f));
+    dy = fmaxf(-6.0f, fminf(dy, 6.0f));
+    float c = cosf(-yaw), sn = sinf(-yaw);
+    float local_dx = dx * c - dy * sn;
+    float local_dy = dx * sn + dy * c;
+    out[0] = fmaxf(-6.0f, fminf(local_dx, 6.0f));
+    out[1] = fmaxf(-6.0f, fminf(local_dy, 6.0f));
+    out[2] = normalize_angle(dyaw);
+}
+
+/* src/level_gen.hpp:16-42 getZeroAction */
+static void zero_action(int model, float *a) {
+    memset(a, 0, 10 * sizeof(float));
+    if (model == DYN_STATE) a[2] = 1.f; /* position {0,0,1} */
+}
+
+/* ------------------------------------------------------------------ */
+/* OBB (src/obb.hpp)                                                   */
+/* ------------------------------------------------------------------ */
+typedef struct { V2 corners[4]; V2 axes[2]; float origin[2]; } OBB;
+
+static OBB obb_from(V3 position, Quat rotation, const float *scale) { /* obb.hpp:12-33 */
+    float theta = quat_to_yaw(rotation);
+    V2 X = { cosf(theta), sinf(theta) };
+    V2 Y = { -sinf(theta), cosf(theta) };
+    X.x *= scale[0]; X.y *= scale[0];
+    Y.x *= scale[1]; Y.y *= scale[1];
+    V2 c = { position.x, position.y };
+    OBB o;
+    o.corners[0].x = c.x - X.x - Y.x; o.corners[0].y = c.y - X.y - Y.y;
+    o.corners[1].x = c.x + X.x - Y.x; o.corners[1].y = c.y + X.y - Y.y;
+    o.corners[2].x = c.x + X.x + Y.x; o.corners[2].y = c.y + X.y + Y.y;
+    o.corners[3].x = c.x - X.x + Y.x; o.corners[3].y = c.y - X.y + Y.y;
+    /* updateAxes obb.hpp:39-50 */
+    o.axes[0].x = o.corners[1].x - o.corners[0].x; o.axes[0].y = o.corners[1].y - o.corners[0].y;
+    o.axes[1].x = o.corners[3].x - o.corners[0].x; o.axes[1].y = o.corners[3].y - o.corners[0].y;
+    for (int a = 0; a < 2; ++a) {
+        float inv = 1.f / v2_len2(o.axes[a].x, o.axes[a].y);
+        o.axes[a].x *= inv; o.axes[a].y *= inv;
+        o.origin[a] = o.corners[0].x * o.axes[a].x + o.corners[0].y * o.axes[a].y;
+    }
+    return o;
+}
+static int obb_overlaps(const OBB *self, const OBB *other) { /* obb.hpp:51-82 */
+    for (int a = 0; a < 2; ++a) {
+        float t = other->corners[0].x * self->axes[a].x + other->corners[0].y * self->axes[a].y;
+        float tMin = t, tMax = t;
+        for (int c = 1; c < 4; ++c) {
+            t = other->corners[c].x * self->axes[a].x + other->corners[c].y * self->axes[a].y;
+            if (t < tMin) tMin = t;
+            else if (t > tMax) tMax = t;
+        }
+        if ((tMin > 1 + self->origin[a]) || (tMax < self->origin[a])) return 0;
+    }
+    return 1;
+}
+static int obb_collided(const OBB *a, const OBB *b) { return obb_overlaps(a, b) && obb_overlaps(b, a); }
+
+/* exported for the known-answer tests (tests/CollisionDetectionTests.cpp) */
+int orc_test_obb_collide(const float *posA, float yawA, const float *scaleA,
+                         const float *posB, float yawB, const float *scaleB) {
+    V3 pa = { posA[0], posA[1], posA[2] }, pb = { posB[0], posB[1], posB[2] };
+    OBB a = obb_from(pa, q_angle_axis_up(yawA), scaleA);
+    OBB b = obb_from(pb, q_angle_axis_up(yawB), scaleB);
+    return obb_collided(&a, &b);
+}
+/* exported for tests/EgocentricRoadObservationTests.cpp */
+void orc_test_reference_frame(const float *refPos2, float refYaw, const float *pos3, float yaw,
+                              const float *scale3, float *out9) {
+    RefFrame rf = { { refPos2[0], refPos2[1] }, q_angle_axis_up(refYaw) };
+    V3 p = { pos3[0], pos3[1], pos3[2] };
+    MapObs m = rf_observation_of(&rf, p, q_angle_axis_up(yaw), scale3, 0, 0.f, -1);
+    memcpy(out9, &m, sizeof(m));
+}
+
+/* ------------------------------------------------------------------ */
+/* world construction (src/level_gen.cpp)                              */
+/* ------------------------------------------------------------------ */
+static void free_map(orc_map *m) {
+    free((void *)m->obj_pos); free((void *)m->obj_vel); free((void *)m->obj_head);
+    free((void *)m->obj_valid); free((void *)m->obj_npos); free((void *)m->obj_size);
+    free((void *)m->obj_goal); free((void *)m->obj_type); free((void *)m->obj_id);
+    free((void *)m->obj_expert); free((void *)m->obj_meta); free((void *)m->road_off);
+    free((void *)m->road_pts); free((void *)m->road_type); free((void *)m->road_id);
+    free((void *)m->road_maptype);
+    memset(m, 0, sizeof(*m));
+}
+static void *dup_mem(const void *p, size_t n) {
+    void *q = malloc(n ? n : 1);
+    if (n) memcpy(q, p, n);
+    return q;
+}
+static void copy_map(orc_map *d, const orc_map *s) {
+    *d = *s;
+    size_t n = (size_t)s->n_obj;
+    d->obj_pos = dup_mem(s->obj_pos, n * 91 * 2 * 4);
+    d->obj_vel = dup_mem(s->obj_vel, n * 91 * 2 * 4);
+    d->obj_head = dup_mem(s->obj_head, n * 91 * 4);
+    d->obj_valid = dup_mem(s->obj_valid, n * 91 * 4);
+    d->obj_npos = dup_mem(s->obj_npos, n * 4);
+    d->obj_size = dup_mem(s->obj_size, n * 3 * 4);
+    d->obj_goal = dup_mem(s->obj_goal, n * 2 * 4);
+    d->obj_type = dup_mem(s->obj_type, n * 4);
+    d->obj_id = dup_mem(s->obj_id, n * 4);
+    d->obj_expert = dup_mem(s->obj_expert, n * 4);
+    d->obj_meta = dup_mem(s->obj_meta, n * 16);
+    size_t r = (size_t)s->n_road;
+    d->road_off = dup_mem(s->road_off, (r + 1) * 4);
+    size_t npts = r ? (size_t)s->road_off[r] : 0;
+    d->road_pts = dup_mem(s->road_pts, npts * 8);
+    d->road_type = dup_mem(s->road_type, r * 4);
+    d->road_id = dup_mem(s->road_id, r * 4);
+    d->road_maptype = dup_mem(s->road_maptype, r * 4);
+}
+
+/* level_gen.cpp:23-30 */
+static void reset_agent_interface(orc_sim *s, int w, int a, int type, int resp, int32_t steps, int32_t done) {
+    size_t i = IDX_WA(s, w, a);
+    s->steps_remaining[i] = (uint32_t)steps;
+    s->done[i] = done;
+    s->reward[i] = 0;
+    int32_t *info = s->info + i * 5;
+    info[0] = info[1] = info[2] = info[3] = 0;
+    info[4] = type;
+    s->resp_type[i] = resp;
+}
+
+/* level_gen.cpp:353-394 */
+static int should_agent_be_created(orc_sim *s, int w, const orc_map *m, int o) {
+    const int32_t *del = s->deleted + (size_t)w * s->A;
+    if (s->p.readFromTracksToPredict) {
+        for (int i = 0; i < s->A; i++) if (del[i] == m->obj_id[o]) return 0;
+        return 1;
+    }
+    if (s->p.IgnoreNonVehicles && (m->obj_type[o] == ET_PEDESTRIAN || m->obj_type[o] == ET_CYCLIST)) return 0;
+    if (s->p.initOnlyValidAgentsAtFirstStep && !m->obj_valid[(size_t)o * 91 + 0]) return 0;
+    for (int i = 0; i < s->A; i++) if (del[i] == m->obj_id[o]) return 0;
+    return 1;
+}
+
+/* level_gen.cpp:56-100 */
+static void populate_expert_trajectory(orc_sim *s, int w, int a, const orc_map *m, int o) {
+    float *t = traj_of(s, w, a);
+    const float mx = s->world_means[(size_t)w * 3 + 0], my = s->world_means[(size_t)w * 3 + 1];
+    int np = m->obj_npos[o];
+    float za[10];
+    zero_action(s->p.dynamicsModel, za);
+    for (int i = 0; i < np; i++) {
+        TR_POS(t, i, 0) = m->obj_pos[((size_t)o * 91 + i) * 2 + 0] - mx;
+        TR_POS(t, i, 1) = m->obj_pos[((size_t)o * 91 + i) * 2 + 1] - my;
+        TR_VEL(t, i, 0) = m->obj_vel[((size_t)o * 91 + i) * 2 + 0];
+        TR_VEL(t, i, 1) = m->obj_vel[((size_t)o * 91 + i) * 2 + 1];
+        TR_HEAD(t, i) = m->obj_head[(size_t)o * 91 + i];
+        TR_VALID(t, i) = (float)(m->obj_valid[(size_t)o * 91 + i] ? 1 : 0);
+        memcpy(TR_INV(t, i), za, sizeof(za));
+    }
+    if (s->p.dynamicsModel == DYN_CLASSIC || s->p.dynamicsModel == DYN_STATE) return;
+    for (int i = np - 2; i >= 0; i--) {
+        /* the "invalid => zero action" branch has no `continue`; the value is overwritten below */
+        Quat rot = q_angle_axis_up(TR_HEAD(t, i));
+        V3 pos = { TR_POS(t, i, 0), TR_POS(t, i, 1), 1 };
+        V3 vel = { TR_VEL(t, i, 0), TR_VEL(t, i, 1), 0 };
+        Quat trot = q_angle_axis_up(TR_HEAD(t, i + 1));
+        if (s->p.dynamicsModel == DYN_BICYCLE) {
+            V3 tvel = { TR_VEL(t, i + 1, 0), TR_VEL(t, i + 1, 1), 0 };
+            inverse_bicycle(rot, vel, trot, tvel, TR_INV(t, i));
+        } else if (s->p.dynamicsModel == DYN_DELTA) {
+            V3 tpos = { TR_POS(t, i + 1, 0), TR_POS(t, i + 1, 1), 1 };
+            inverse_delta(rot, pos, trot, tpos, TR_INV(t, i));
+        }
+    }
+}
+
+static void set_road_props(orc_sim *s, int w, int idx, V3 pos, Quat rot, float d0, float d1, float d2,
+                           int type, int id, int mapType) { /* level_gen.hpp:44-65 */
+    World *wd = &s->worlds[w];
+    RoadEnt *r = &wd->roads[idx];
+    r->pos = pos; r->rot = rot; r->scale[0] = d0; r->scale[1] = d1; r->scale[2] = d2;
+    r->type = type; r->id = id; r->mapType = mapType;
+    float *mo = s->map_obs + ((size_t)w * MAX_ROADS_ENT + idx) * 9;
+    mo[0] = pos.x; mo[1] = pos.y; mo[2] = d0; mo[3] = d1; mo[4] = d2;
+    mo[5] = quat_to_yaw(rot); mo[6] = (float)type; mo[7] = (float)(uint32_t)id; mo[8] = (float)mapType;
+}
+
+/* level_gen.cpp:166-185 */
+static void make_road_edge(orc_sim *s, int w, int idx, const orc_map *m, int r, int j) {
+    const float *p1 = m->road_pts + ((size_t)m->road_off[r] + j) * 2;
+    const float *p2 = p1 + 2;
+    const float mx = s->world_means[(size_t)w * 3 + 0], my = s->world_means[(size_t)w * 3 + 1];
+    int type = m->road_type[r];
+    float z = 1 + (type == ET_ROADEDGE ? 0.1f : -0.1f);
+    V3 start = { p1[0] - mx, p1[1] - my, z };
+    V3 end = { p2[0] - mx, p2[1] - my, z };
+    V3 pos = { (start.x + end.x) / 2, (start.y + end.y) / 2, z };
+    Quat rot = q_angle_axis_up(atan2f(end.y - start.y, end.x - start.x));
+    float dist = v3_len(start.x - end.x, start.y - end.y, start.z - end.z);
+    set_road_props(s, w, idx, pos, rot, dist / 2, 0.1f, 0.1f, type, m->road_id[r], m->road_maptype[r]);
+}
+
+/* level_gen.cpp:187-241 */
+static float calculate_distance(float x1, float y1, float x2, float y2) {
+    /* sqrt(pow(x2 - x1, 2) + pow(y2 - y1, 2)) evaluated in double, returned as float */
+    return (float)sqrt(pow((double)(x2 - x1), 2) + pow((double)(y2 - y1), 2));
+}
+static void make_cube(orc_sim *s, int w, int idx, const orc_map *m, int r) {
+    const float *g = m->road_pts + (size_t)m->road_off[r] * 2;
+    float px[4] = { g[0], g[2], g[4], g[6] }, py[4] = { g[1], g[3], g[5], g[7] };
+    float lengths[4];
+    for (int i = 0; i < 4; ++i) lengths[i] = calculate_distance(px[i], py[i], px[(i + 1) % 4], py[(i + 1) % 4]);
+    int maxI = 0, minI = 0;
+    for (int i = 1; i < 4; ++i) {
+        if (lengths[i] > lengths[maxI]) maxI = i;
+        if (lengths[i] < lengths[minI]) minI = i;
+    }
+    float sx = px[maxI], sy = py[maxI], ex = px[(maxI + 1) % 4], ey = py[(maxI + 1) % 4];
+    float angle = atan2f(ey - sy, ex - sx);
+    float sum_x = 0.0f, sum_y = 0.0f;
+    for (int i = 0; i < 4; i++) { sum_x += px[i]; sum_y += py[i]; }
+    const float mx = s->world_means[(size_t)w * 3 + 0], my = s->world_means[(size_t)w * 3 + 1];
+    V3 pos = { sum_x / 4 - mx, sum_y / 4 - my, 1 + -0.1f };
+    set_road_props(s, w, idx, pos, q_angle_axis_up(angle), lengths[maxI] / 2, lengths[minI] / 2, 0.1f,
+                   m->road_type[r], m->road_id[r], m->road_maptype[r]);
+}
+/* level_gen.cpp:243-256 */
+static void make_stop_sign(orc_sim *s, int w, int idx, const orc_map *m, int r) {
+    const float *g = m->road_pts + (size_t)m->road_off[r] * 2;
+    const float mx = s->world_means[(size_t)w * 3 + 0], my = s->world_means[(size_t)w * 3 + 1];
+    V3 pos = { g[0] - mx, g[1] - my, 1 };
+    set_road_props(s, w, idx, pos, q_angle_axis_up(0), 0.2f, 0.2f, 1.f, ET_STOPSIGN, m->road_id[r],
+                   m->road_maptype[r]);
+}
+
+static void write_zero_rows(orc_sim *s, int w, int a) { /* level_gen.cpp:308-329 */
+    size_t i = IDX_WA(s, w, a);
+    MapObs z = mapobs_zero();
+    for (int k = 0; k < K_MAP; k++) memcpy(s->agent_map_obs + (i * K_MAP + k) * 9, &z, sizeof(z));
+    float so[8] = { 0, 0, 0, 0, 0, 0, 0, -1.f };
+    memcpy(s->self_obs + i * 8, so, sizeof(so));
+    float po[9] = { 0, 0, 0, 0, 0, 0, 0, (float)ET_NONE, -1.f };
+    for (int k = 0; k < s->A - 1; k++) memcpy(s->partner_obs + (i * (s->A - 1) + k) * 9, po, sizeof(po));
+}
+
+/* level_gen.cpp:396-465 createPersistentEntities (+ createPaddingEntities :308-336) */
+static void create_persistent_entities(orc_sim *s, int w) {
+    World *wd = &s->worlds[w];
+    const orc_map *m = &wd->map;
+    for (int i = 0; i < 32; i++) {
+        s->map_name[(size_t)w * 32 + i] = (int32_t)(uint32_t)(char)m->name[i];
+        s->scenario_id[(size_t)w * 32 + i] = (int32_t)(uint32_t)(char)m->scenario_id[i];
+    }
+    wd->num_controlled = 0;
+    wd->reset_map = 0;
+    s->world_means[(size_t)w * 3 + 0] = m->mean[0];
+    s->world_means[(size_t)w * 3 + 1] = m->mean[1];
+    s->world_means[(size_t)w * 3 + 2] = 0;
+    const float mx = m->mean[0], my = m->mean[1];
+
+    int agentIdx = 0;
+    for (int o = 0; o < m->n_obj && agentIdx < s->A; ++o) {
+        if (!should_agent_be_created(s, w, m, o)) continue;
+        /* createAgent level_gen.cpp:131-164 */
+        AgentEnt *ag = &wd->agents[agentIdx];
+        size_t i = IDX_WA(s, w, agentIdx);
+        memset(ag, 0, sizeof(*ag));
+        ag->size[0] = m->obj_size[o * 3 + 0]; ag->size[1] = m->obj_size[o * 3 + 1]; ag->size[2] = m->obj_size[o * 3 + 2];
+        ag->scale[0] = ag->size[0] / 2; ag->scale[1] = ag->size[1] / 2; ag->scale[2] = 1;
+        ag->scale[0] *= 0.7f; ag->scale[1] *= 0.7f; ag->scale[2] *= 0.7f;
+        ag->etype = m->obj_type[o];
+        ag->goal.x = m->obj_goal[o * 2 + 0] - mx;
+        ag->goal.y = m->obj_goal[o * 2 + 1] - my;
+        s->agent_id[i] = m->obj_id[o];
+        /* Trajectory table rows are zero for fresh interface entities */
+        memset(traj_of(s, w, agentIdx), 0, TRAJ_F * sizeof(float));
+        populate_expert_trajectory(s, w, agentIdx, m, o);
+        float *t = traj_of(s, w, agentIdx);
+        /* isAgentStatic level_gen.cpp:102-113 (readFromTracksToPredict: evident intent, uses the
+         * object's own metadata; the reference reads the interface row before assigning it) */
+        int is_static;
+        if (s->p.readFromTracksToPredict && m->obj_meta[o * 4 + 2] != -1) {
+            is_static = 0;
+        } else {
+            float d = v2_len(ag->goal.x - TR_POS(t, 0, 0), ag->goal.y - TR_POS(t, 0, 1));
+            is_static = (!s->p.isStaticAgentControlled) && (d < 0.2f);
+        }
+        ag->resp = is_static ? RESP_STATIC : RESP_DYNAMIC;
+        /* isAgentControllable level_gen.cpp:115-129 */
+        int ctrl;
+        if (s->p.readFromTracksToPredict) {
+            ctrl = ((uint32_t)wd->num_controlled < s->p.maxNumControlledAgents) && (m->obj_meta[o * 4 + 2] != -1);
+        } else {
+            ctrl = ((uint32_t)wd->num_controlled < s->p.maxNumControlledAgents) && (TR_VALID(t, 0) != 0.f) &&
+                   (ag->resp == RESP_DYNAMIC) && !m->obj_expert[o];
+        }
+        s->controlled[i] = ctrl;
+        wd->num_controlled += ctrl;
+        memcpy(s->metadata + i * 4, m->obj_meta + o * 4, 16);
+        agentIdx++;
+    }
+    wd->num_agents = agentIdx;
+
+    /* roads: createRoadEntities level_gen.cpp:258-300 */
+    int roadIdx = 0;
+    for (int r = 0; r < m->n_road && roadIdx < MAX_ROADS_ENT; r++) {
+        int type = m->road_type[r];
+        int npts = m->road_off[r + 1] - m->road_off[r];
+        if (type == ET_ROADEDGE || type == ET_ROADLINE || type == ET_ROADLANE) {
+            for (int j = 1; j <= npts - 1; j++) {
+                make_road_edge(s, w, roadIdx++, m, r, j - 1);
+                if (roadIdx >= MAX_ROADS_ENT) break;
+            }
+        } else if (type == ET_CROSSWALK || type == ET_SPEEDBUMP) {
+            if (npts >= 4) make_cube(s, w, roadIdx++, m, r);
+        } else if (type == ET_STOPSIGN) {
+            if (npts >= 1) make_stop_sign(s, w, roadIdx++, m, r);
+        }
+    }
+    wd->num_roads = roadIdx;
+    s->shape[(size_t)w * 2 + 0] = wd->num_agents;
+    s->shape[(size_t)w * 2 + 1] = wd->num_roads;
+
+    /* createPaddingEntities level_gen.cpp:308-336 */
+    for (int a = wd->num_agents; a < s->A; ++a) {
+        size_t i = IDX_WA(s, w, a);
+        s->agent_id[i] = -1;
+        reset_agent_interface(s, w, a, ET_NONE, RESP_STATIC, 0, 1);
+        s->controlled[i] = 0;
+        write_zero_rows(s, w, a);
+        memset(traj_of(s, w, a), 0, TRAJ_F * sizeof(float));
+        for (int k = 0; k < 4; k++) s->metadata[i * 4 + k] = -1;
+    }
+    MapObs z = mapobs_zero();
+    for (int r = wd->num_roads; r < MAX_ROADS_ENT; ++r)
+        memcpy(s->map_obs + ((size_t)w * MAX_ROADS_ENT + r) * 9, &z, sizeof(z));
+}
+
+/* level_gen.cpp:32-54 resetAgent */
+static void reset_agent(orc_sim *s, int w, int a) {
+    World *wd = &s->worlds[w];
+    AgentEnt *ag = &wd->agents[a];
+    float *t = traj_of(s, w, a);
+    ag->pos.x = TR_POS(t, 0, 0); ag->pos.y = TR_POS(t, 0, 1); ag->pos.z = 1;
+    ag->rot = q_angle_axis_up(TR_HEAD(t, 0));
+    memset(&ag->vel_lin, 0, sizeof(V3)); memset(&ag->vel_ang, 0, sizeof(V3));
+    if (ag->resp != RESP_STATIC) { ag->vel_lin.x = TR_VEL(t, 0, 0); ag->vel_lin.y = TR_VEL(t, 0, 1); }
+    zero_action(s->p.dynamicsModel, s->action + IDX_WA(s, w, a) * 10);
+    reset_agent_interface(s, w, a, ag->etype, ag->resp, EPISODE_LEN, 0);
+    ag->collided = 0;
+}
+
+/* sim.cpp:126-166 initWorld / resetSystem */
+static void init_world(orc_sim *s, int w) {
+    World *wd = &s->worlds[w];
+    if (wd->reset_map == 1) {
+        create_persistent_entities(s, w);
+        wd->reset_map = 0;
+    }
+    for (int a = 0; a < wd->num_agents; a++) reset_agent(s, w, a);
+}
+static void reset_system(orc_sim *s, int w) {
+    World *wd = &s->worlds[w];
+    if (wd->reset_flag == 0) return;
+    wd->reset_flag = 0;
+    /* resetMap==1: cleanupWorld + createPersistentEntities inside initWorld */
+    init_world(s, w);
+}
+
+/* ------------------------------------------------------------------ */
+/* step systems (src/sim.cpp)                                          */
+/* ------------------------------------------------------------------ */
+static inline int current_step(uint32_t t) { /* sim.cpp:23-25; index kept inside the row */
+    int64_t k = (int64_t)EPISODE_LEN - (int64_t)t;
+    if (k < 0) k = EPISODE_LEN; /* t wrapped after episode end: out of contract, clamp */
+    if (k > EPISODE_LEN) k = EPISODE_LEN;
+    return (int)k;
+}
+
+/* sim.cpp:294-383 */
+static void movement_system(orc_sim *s, int w, int a) {
+    World *wd = &s->worlds[w];
+    AgentEnt *ag = &wd->agents[a];
+    size_t i = IDX_WA(s, w, a);
+    if (ag->collided) {
+        switch (s->p.collisionBehaviour) {
+        case COL_STOP:
+            s->done[i] = 1;
+            memset(&ag->vel_lin, 0, sizeof(V3)); memset(&ag->vel_ang, 0, sizeof(V3));
+            break;
+        case COL_REMOVED:
+            s->done[i] = 1;
+            ag->pos.x = PAD_X; ag->pos.y = PAD_Y; ag->pos.z = PAD_Z;
+            memset(&ag->vel_lin, 0, sizeof(V3)); memset(&ag->vel_ang, 0, sizeof(V3));
+            break;
+        case COL_IGNORE:
+            ag->collided = 0;
+            s->info[i * 5 + 0] = s->info[i * 5 + 1] = s->info[i * 5 + 2] = 0;
+            break;
+        }
+    }
+    if (ag->resp == RESP_STATIC) return;
+    if (s->done[i] && ag->resp != RESP_STATIC) {
+        ag->pos.x = PAD_X; ag->pos.y = PAD_Y; ag->pos.z = PAD_Z;
+        memset(&ag->vel_lin, 0, sizeof(V3)); memset(&ag->vel_ang, 0, sizeof(V3));
+        return;
+    }
+    if (s->controlled[i]) {
+        float *action = s->action + i * 10;
+        switch (s->p.dynamicsModel) {
+        case DYN_BICYCLE: forward_bicycle(action, &ag->rot, &ag->pos, &ag->vel_lin, &ag->vel_ang); break;
+        case DYN_DELTA: forward_delta(action, &ag->rot, &ag->pos, &ag->vel_lin, &ag->vel_ang); break;
+        case DYN_CLASSIC: forward_kinematics(action, ag->size, &ag->rot, &ag->pos, &ag->vel_lin, &ag->vel_ang); break;
+        case DYN_STATE: forward_state(action, &ag->rot, &ag->pos, &ag->vel_lin, &ag->vel_ang); break;
+        }
+    } else {
+        const float *t = traj_of(s, w, a);
+        int k = current_step(s->steps_remaining[i]);
+        /* k == 91 cannot be reached here: t == 0 implies done (handled above) */
+        ag->pos.x = t[k * 2 + 0]; ag->pos.y = t[k * 2 + 1]; ag->pos.z = 1;
+        ag->vel_lin.x = TR_VEL(t, k, 0); ag->vel_lin.y = TR_VEL(t, k, 1); ag->vel_lin.z = 0;
+        memset(&ag->vel_ang, 0, sizeof(V3));
+        ag->rot = q_angle_axis_up(TR_HEAD(t, k));
+    }
+}
+
+/* sim.hpp:88-102 collisionPairs */
+static int type_pair_filtered(int a, int b) {
+    static const int pairs[14][2] = {
+        { ET_PEDESTRIAN, ET_ROADEDGE }, { ET_PEDESTRIAN, ET_ROADLINE }, { ET_PEDESTRIAN, ET_ROADLANE },
+        { ET_PEDESTRIAN, ET_CROSSWALK }, { ET_PEDESTRIAN, ET_SPEEDBUMP },
+        { ET_CYCLIST, ET_ROADEDGE }, { ET_CYCLIST, ET_ROADLINE }, { ET_CYCLIST, ET_ROADLANE },
+        { ET_CYCLIST, ET_CROSSWALK }, { ET_CYCLIST, ET_SPEEDBUMP },
+        { ET_VEHICLE, ET_CROSSWALK }, { ET_VEHICLE, ET_SPEEDBUMP }, { ET_VEHICLE, ET_ROADLINE },
+        { ET_VEHICLE, ET_ROADLANE } };
+    /* the array has 20 slots; the 6 unfilled ones are {None, None} and also match */
+    if (a == ET_NONE && b == ET_NONE) return 1;
+    for (int k = 0; k < 14; k++)
+        if ((pairs[k][0] == a && pairs[k][1] == b) || (pairs[k][0] == b && pairs[k][1] == a)) return 1;
+    return 0;
+}
+
+/* sim.cpp:631-662 */
+static int invalid_expert_or_done(orc_sim *s, int w, int a) {
+    size_t i = IDX_WA(s, w, a);
+    if (!s->controlled[i]) {
+        int k = current_step(s->steps_remaining[i]);
+        const float *t = traj_of(s, w, a);
+        if (!(t[5 * TRAJ_LEN + k] != 0.f)) return 1; /* valids[k]; k==91 reads inverseActions[0] like the reference */
+    } else {
+        if (s->done[i] && !s->worlds[w].agents[a].collided) return 1;
+    }
+    return 0;
+}
+
+static void mark_collision(orc_sim *s, int w, int a, int otherType) { /* sim.cpp:708-744 */
+    size_t i = IDX_WA(s, w, a);
+    s->worlds[w].agents[a].collided = 1;
+    if (otherType > ET_NONE && otherType <= ET_STOPSIGN) s->info[i * 5 + 0] = 1;
+    else if (otherType == ET_VEHICLE) s->info[i * 5 + 1] = 1;
+    else if (otherType <= ET_CYCLIST) s->info[i * 5 + 2] = 1;
+}
+
+/*
+ * sim.cpp:792-801: Madrona broadphase (absent) + collisionDetectionSystem (sim.cpp:628-747).
+ * Restated as: every pair whose 3-D AABBs can overlap and where not both bodies are Static gets
+ * the exact 2-D OBB test.  Agents teleported to kPaddingPosition (z = FLT_MAX) overlap nothing
+ * (tests/test_expert.py:48-60 pins zero collisions among teleported experts).  A conservative
+ * bounding-circle prefilter stands in for the BVH; it never removes a pair the OBB test accepts.
+ */
+static void collision_system(orc_sim *s, int w) {
+    World *wd = &s->worlds[w];
+    int n = wd->num_agents;
+    OBB boxes[MAXA]; float rad[MAXA]; int active[MAXA];
+    for (int a = 0; a < n; a++) {
+        AgentEnt *ag = &wd->agents[a];
+        active[a] = !(ag->pos.z == PAD_Z) && !invalid_expert_or_done(s, w, a);
+        if (active[a]) {
+            boxes[a] = obb_from(ag->pos, ag->rot, ag->scale);
+            rad[a] = sqrtf(ag->scale[0] * ag->scale[0] + ag->scale[1] * ag->scale[1]);
+        }
+    }
+    for (int a = 0; a < n; a++) {
+        if (!active[a]) continue;
+        AgentEnt *A = &wd->agents[a];
+        for (int b = a + 1; b < n; b++) {
+            if (!active[b]) continue;
+            AgentEnt *B = &wd->agents[b];
+            if (A->resp == RESP_STATIC && B->resp == RESP_STATIC) continue;
+            float dx = A->pos.x - B->pos.x, dy = A->pos.y - B->pos.y, rr = (rad[a] + rad[b]) * 1.001f + 0.01f;
+            if (dx * dx + dy * dy > rr * rr) continue;
+            if (!obb_collided(&boxes[a], &boxes[b])) continue;
+            if (type_pair_filtered(A->etype, B->etype)) continue;
+            mark_collision(s, w, a, B->etype);
+            mark_collision(s, w, b, A->etype);
+        }
+        if (A->resp == RESP_STATIC) continue;
+        for (int r = 0; r < wd->num_roads; r++) {
+            RoadEnt *R = &wd->roads[r];
+            if (type_pair_filtered(A->etype, R->type)) continue; /* filter first: result-equivalent */
+            float dx = A->pos.x - R->pos.x, dy = A->pos.y - R->pos.y;
+            float rb = sqrtf(R->scale[0] * R->scale[0] + R->scale[1] * R->scale[1]);
+            float rr = (rad[a] + rb) * 1.001f + 0.01f;
+            if (dx * dx + dy * dy > rr * rr) continue;
+            OBB ro = obb_from(R->pos, R->rot, R->scale);
+            if (!obb_collided(&boxes[a], &ro)) continue;
+            mark_collision(s, w, a, R->type);
+        }
+    }
+}
+
+/* sim.cpp:560-587 */
+static void reward_system(orc_sim *s, int w, int a) {
+    AgentEnt *ag = &s->worlds[w].agents[a];
+    size_t i = IDX_WA(s, w, a);
+    float dist = v2_len(ag->pos.x - ag->goal.x, ag->pos.y - ag->goal.y);
+    if (s->p.rewardType == REW_DISTANCE) s->reward[i] = -dist;
+    else if (s->p.rewardType == REW_ONGOAL) s->reward[i] = (dist < s->p.distanceToGoalThreshold) ? 1.f : 0.f;
+    /* Dense: assert(false) in the reference; leave the reward unchanged */
+}
+
+/* sim.cpp:597-626 */
+static void done_system(orc_sim *s, int w, int a) {
+    AgentEnt *ag = &s->worlds[w].agents[a];
+    size_t i = IDX_WA(s, w, a);
+    int32_t num_remaining = (int32_t)s->steps_remaining[i];
+    if (num_remaining == EPISODE_LEN && s->done[i] != 1) { s->done[i] = 0; return; }
+    else if (num_remaining == 0) s->done[i] = 1;
+    if (s->done[i] != 1 || s->info[i * 5 + 3] != 1) {
+        float dist = v2_len(ag->pos.x - ag->goal.x, ag->pos.y - ag->goal.y);
+        if (dist < s->p.distanceToGoalThreshold) { s->done[i] = 1; s->info[i * 5 + 3] = 1; }
+    }
+}
+
+/* sim.cpp:168-186 */
+static void collect_self_obs(orc_sim *s, int w, int a) {
+    AgentEnt *ag = &s->worlds[w].agents[a];
+    size_t i = IDX_WA(s, w, a);
+    float *o = s->self_obs + i * 8;
+    o[0] = v3_len(ag->vel_lin.x, ag->vel_lin.y, ag->vel_lin.z);
+    o[1] = ag->size[0]; o[2] = ag->size[1]; o[3] = ag->size[2];
+    V3 g = { ag->goal.x - ag->pos.x, ag->goal.y - ag->pos.y, 0 };
+    V3 r = q_rotate(q_inv(ag->rot), g);
+    o[4] = r.x; o[5] = r.y;
+    o[6] = ag->collided ? 1.f : 0.f;
+    o[7] = (float)s->agent_id[i];
+}
+
+/* sim.cpp:769-783 */
+static void collect_abs_obs(orc_sim *s, int w, int a) {
+    AgentEnt *ag = &s->worlds[w].agents[a];
+    size_t i = IDX_WA(s, w, a);
+    float *o = s->abs_obs + i * 14;
+    o[0] = ag->pos.x; o[1] = ag->pos.y; o[2] = ag->pos.z;
+    o[3] = ag->rot.w; o[4] = ag->rot.x; o[5] = ag->rot.y; o[6] = ag->rot.z;
+    o[7] = quat_to_yaw(ag->rot);
+    o[8] = ag->goal.x; o[9] = ag->goal.y;
+    o[10] = ag->size[0]; o[11] = ag->size[1]; o[12] = ag->size[2];
+    o[13] = (float)s->agent_id[i];
+}
+
+/* sim.cpp:188-240 */
+static void collect_partner_obs(orc_sim *s, int w, int a) {
+    if (s->p.disableClassicalObs) return;
+    World *wd = &s->worlds[w];
+    AgentEnt *ag = &wd->agents[a];
+    float *out = s->partner_obs + IDX_WA(s, w, a) * (size_t)(s->A - 1) * 9;
+    int k = 0;
+    for (int j = 0; j < wd->num_agents; j++) { /* OtherAgents order: level_gen.cpp:450-464 */
+        if (j == a) continue;
+        AgentEnt *ot = &wd->agents[j];
+        V3 rel = { ot->pos.x - ag->pos.x, ot->pos.y - ag->pos.y, 0 };
+        V3 r = q_rotate(q_inv(ag->rot), rel);
+        float speed = v3_len(ot->vel_lin.x, ot->vel_lin.y, ot->vel_lin.z);
+        float heading = quat_to_yaw(q_mul(q_inv(ag->rot), ot->rot));
+        float *o = out + (size_t)k * 9;
+        if (v2_len(r.x, r.y) > s->p.observationRadius) {
+            o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_NONE; o[8] = -1.f;
+        } else {
+            o[0] = speed; o[1] = r.x; o[2] = r.y; o[3] = heading;
+            o[4] = ot->size[0]; o[5] = ot->size[1]; o[6] = ot->size[2];
+            o[7] = (float)ot->etype; o[8] = (float)s->agent_id[IDX_WA(s, w, j)];
+        }
+        k++;
+    }
+    for (; k < s->A - 1; k++) {
+        float *o = out + (size_t)k * 9;
+        o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_NONE; o[8] = -2.f;
+    }
+}
+
+/* ---- SGI heap on MapObs keyed by position.length2 (src/binary_heap.hpp, src/knn.hpp:15-17) ---- */
+static inline int mo_cmp(const MapObs *l, const MapObs *r) {
+    return v2_len2(l->x, l->y) < v2_len2(r->x, r->y);
+}
+static void heap_push(MapObs *first, int holeIndex, int topIndex, MapObs x) { /* __push_heap */
+    int parent = (holeIndex - 1) / 2;
+    while (holeIndex > topIndex && mo_cmp(first + parent, &x)) {
+        first[holeIndex] = first[parent];
+        holeIndex = parent;
+        parent = (holeIndex - 1) / 2;
+    }
+    first[holeIndex] = x;
+}
+static void heap_adjust(MapObs *first, int holeIndex, int len, MapObs x) { /* __adjust_heap (comp) */
+    int topIndex = holeIndex;
+    int secondChild = 2 * holeIndex + 2;
+    while (secondChild < len) {
+        if (mo_cmp(first + secondChild, first + (secondChild - 1))) secondChild--;
+        first[holeIndex] = first[secondChild];
+        holeIndex = secondChild;
+        secondChild = 2 * (secondChild + 1);
+    }
+    if (secondChild == len) {
+        first[holeIndex] = first[secondChild - 1];
+        holeIndex = secondChild - 1;
+    }
+    heap_push(first, holeIndex, topIndex, x);
+}
+static void heap_make(MapObs *first, int len) { /* __make_heap */
+    if (len < 2) return;
+    int parent = (len - 2) / 2;
+    while (1) {
+        heap_adjust(first, parent, len, first[parent]);
+        if (parent == 0) return;
+        parent--;
+    }
+}
+static void heap_pop(MapObs *first, int len) { /* pop_heap(first, first+len) */
+    MapObs x = first[len - 1];
+    first[len - 1] = first[0];
+    heap_adjust(first, 0, len - 1, x);
+}
+
+static int radius_filter(MapObs *heap, int K, float radius) { /* knn.hpp:83-97 */
+    int newBeyond = K, idx = 0;
+    while (idx < newBeyond) {
+        if (v2_len(heap[idx].x, heap[idx].y) <= radius) { ++idx; continue; }
+        heap[idx] = heap[--newBeyond];
+    }
+    return newBeyond;
+}
+static void fill_zeros(MapObs *b, MapObs *e) { /* knn.hpp:19-28: id and mapType stay 0 */
+    MapObs z = { 0, 0, 0, 0, 0, 0, (float)ET_NONE, 0, 0 };
+    while (b < e) *b++ = z;
+}
+
+static inline MapObs road_obs(const RefFrame *rf, const RoadEnt *r) {
+    /* RoadMapId.id is int32 written from a uint32 (level_gen.hpp:58), then static_cast<float> */
+    return rf_observation_of(rf, r->pos, r->rot, r->scale, r->type, (float)(int32_t)r->id, r->mapType);
+}
+
+/* knn.hpp:103-158 */
+static void select_k_nearest(orc_sim *s, int w, const RefFrame *rf, MapObs *heap, int64_t *inserts) {
+    World *wd = &s->worlds[w];
+    const int roadCount = wd->num_roads;
+    const int K = K_MAP;
+    int first = roadCount < K ? roadCount : K;
+    for (int i = 0; i < first; ++i) heap[i] = road_obs(rf, &wd->roads[i]);
+    if (roadCount < K) {
+        int nb = radius_filter(heap, roadCount, s->p.observationRadius);
+        fill_zeros(heap + nb, heap + K);
+        return;
+    }
+    heap_make(heap, K);
+    for (int roadIdx = K; roadIdx < roadCount; ++roadIdx) {
+        MapObs cur = road_obs(rf, &wd->roads[roadIdx]);
+        if (!mo_cmp(&cur, &heap[0])) continue;
+        heap_pop(heap, K);
+        heap[K - 1] = cur;
+        heap_push(heap, K - 1, 0, heap[K - 1]);
+        (*inserts)++;
+    }
+    int nb = radius_filter(heap, K, s->p.observationRadius);
+    fill_zeros(heap + nb, heap + K);
+}
+
+/* sim.cpp:242-280 */
+static void collect_map_obs(orc_sim *s, int w, int a, int64_t *inserts) {
+    if (s->p.disableClassicalObs) return;
+    World *wd = &s->worlds[w];
+    AgentEnt *ag = &wd->agents[a];
+    MapObs *out = (MapObs *)(s->agent_map_obs + IDX_WA(s, w, a) * (size_t)K_MAP * 9);
+    RefFrame rf = { { ag->pos.x, ag->pos.y }, ag->rot };
+    if (s->p.roadObservationAlgorithm == ROADS_KNN) {
+        select_k_nearest(s, w, &rf, out, inserts);
+        return;
+    }
+    int arrIndex = 0, roadIdx = 0;
+    while (roadIdx < wd->num_roads && arrIndex < K_MAP) {
+        const RoadEnt *r = &wd->roads[roadIdx++];
+        float dist = rf_distance_to(&rf, r->pos);
+        if (dist > s->p.observationRadius) continue;
+        out[arrIndex++] = road_obs(&rf, r);
+    }
+    while (arrIndex < K_MAP) out[arrIndex++] = mapobs_zero();
+}
+
+/* src/rasterizer.hpp:12-78 */
+static void rasterize(float *grid, float cx, float cy, float yaw, float length, float width, size_t type,
+                      float radius, int resolution) {
+    float half_w = width / 2.0f, half_l = length / 2.0f;
+    float scale_px = (2 * radius) / resolution;
+    float scale_m = resolution / (2 * radius);
+    int gx = (int)((cx + radius) * scale_m), gy = (int)((cy + radius) * scale_m);
+    gx = gx < 0 ? 0 : (gx > resolution - 1 ? resolution - 1 : gx);
+    gy = gy < 0 ? 0 : (gy > resolution - 1 ? resolution - 1 : gy);
+    float max_side = half_w > half_l ? half_w : half_l;
+    int box_radius = (int)ceilf(sqrtf(2 * (max_side * max_side)) / scale_px);
+    float cos_yaw = cosf(-yaw), sin_yaw = sinf(-yaw);
+    for (int dy = -box_radius; dy <= box_radius; dy++)
+        for (int dx = -box_radius; dx <= box_radius; dx++) {
+            int x = gx + dx, y = gy + dy;
+            if (x < 0 || x >= resolution || y < 0 || y >= resolution) continue;
+            float px = x * scale_px - radius, py = y * scale_px - radius;
+            float ldx = px - cx, ldy = py - cy;
+            float lx = ldx * cos_yaw - ldy * sin_yaw;
+            float ly = ldx * sin_yaw + ldy * cos_yaw;
+            const float epsilon = 1e-3f;
+            if (fabsf(lx) <= half_l + epsilon && fabsf(ly) <= half_w + epsilon)
+                grid[(size_t)y * resolution + x] = (float)type;
+        }
+}
+
+/* sim.cpp:462-555 */
+static void collect_bev_obs(orc_sim *s, int w, int a) {
+    if (s->p.disableClassicalObs || !s->bev) return;
+    World *wd = &s->worlds[w];
+    AgentEnt *ag = &wd->agents[a];
+    float *grid = s->bev + IDX_WA(s, w, a) * (size_t)BEV_RES * BEV_RES;
+    memset(grid, 0, sizeof(float) * BEV_RES * BEV_RES);
+    RefFrame rf = { { ag->pos.x, ag->pos.y }, ag->rot };
+    const float R = s->p.observationRadius;
+    int roadIdx = 0, arrIndex = 0;
+    while (roadIdx < wd->num_roads && arrIndex < K_MAP) {
+        const RoadEnt *r = &wd->roads[roadIdx++];
+        MapObs mo = road_obs(&rf, r);
+        float dist = rf_distance_to(&rf, r->pos);
+        if (dist > R) continue;
+        float d1 = mo.d1;
+        float minw = (2 * R / BEV_RES);
+        if (minw > d1) d1 = minw;
+        rasterize(grid, mo.x, mo.y, mo.heading, mo.d0, d1, (size_t)mo.type, R, BEV_RES);
+        arrIndex++;
+    }
+    for (int j = 0; j < wd->num_agents; j++) {
+        if (j == a) continue;
+        AgentEnt *ot = &wd->agents[j];
+        V3 rel = { ot->pos.x - ag->pos.x, ot->pos.y - ag->pos.y, 0 };
+        V3 r = q_rotate(q_inv(ag->rot), rel);
+        float heading = quat_to_yaw(q_mul(q_inv(ag->rot), ot->rot));
+        if (v2_len(r.x, r.y) > R) continue;
+        rasterize(grid, r.x, r.y, heading, ot->size[0], ot->size[1], (size_t)ot->etype, R, BEV_RES);
+    }
+}
+
+/* sim.cpp:785-943 setupRestOfTasks */
+static void rest_of_tasks(orc_sim *s, int w, int decrementStep, int64_t *inserts) {
+    World *wd = &s->worlds[w];
+    collision_system(s, w);
+    for (int a = 0; a < wd->num_agents; a++) reward_system(s, w, a);
+    if (decrementStep)
+        for (int a = 0; a < wd->num_agents; a++) --s->steps_remaining[IDX_WA(s, w, a)];
+    for (int a = 0; a < wd->num_agents; a++) done_system(s, w, a);
+    for (int a = 0; a < wd->num_agents; a++) {
+        collect_self_obs(s, w, a);
+        collect_partner_obs(s, w, a);
+        collect_map_obs(s, w, a, inserts);
+        collect_bev_obs(s, w, a);
+        collect_abs_obs(s, w, a);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* public API                                                          */
+/* ------------------------------------------------------------------ */
+orc_sim *orc_create(const orc_params *p, int num_worlds, int max_agents) {
+    if (max_agents < 2 || max_agents > MAXA || num_worlds < 1) return NULL;
+    orc_sim *s = calloc(1, sizeof(*s));
+    s->p = *p; s->W = num_worlds; s->A = max_agents;
+    size_t WA = (size_t)num_worlds * max_agents;
+    s->worlds = calloc(num_worlds, sizeof(World));
+    for (int w = 0; w < num_worlds; w++) s->worlds[w].roads = calloc(MAX_ROADS_ENT, sizeof(RoadEnt));
+    s->action = calloc(WA * 10, 4); s->reward = calloc(WA, 4); s->done = calloc(WA, 4);
+    s->info = calloc(WA * 5, 4); s->self_obs = calloc(WA * 8, 4); s->abs_obs = calloc(WA * 14, 4);
+    s->partner_obs = calloc(WA * (max_agents - 1) * 9, 4);
+    s->agent_map_obs = calloc(WA * K_MAP * 9, 4);
+    s->map_obs = calloc((size_t)num_worlds * MAX_ROADS_ENT * 9, 4);
+    s->lidar = calloc(WA * 3 * LIDAR_N * 4, 4);
+    s->bev = p->enableBev ? calloc(WA * BEV_RES * BEV_RES, 4) : NULL;
+    s->steps_remaining = calloc(WA, 4); s->shape = calloc((size_t)num_worlds * 2, 4);
+    s->controlled = calloc(WA, 4); s->resp_type = calloc(WA, 4);
+    s->trajectory = calloc(WA * TRAJ_F, 4); s->world_means = calloc((size_t)num_worlds * 3, 4);
+    s->metadata = calloc(WA * 4, 4); s->deleted = malloc(WA * 4);
+    s->map_name = calloc((size_t)num_worlds * 32, 4); s->scenario_id = calloc((size_t)num_worlds * 32, 4);
+    s->agent_id = calloc(WA, 4);
+    for (size_t i = 0; i < WA; i++) s->deleted[i] = -1; /* sim.cpp:1003-1006 */
+    return s;
+}
+
+void orc_destroy(orc_sim *s) {
+    if (!s) return;
+    for (int w = 0; w < s->W; w++) { if (s->worlds[w].has_map) free_map(&s->worlds[w].map); free(s->worlds[w].roads); }
+    free(s->worlds); free(s->action); free(s->reward); free(s->done); free(s->info); free(s->self_obs);
+    free(s->abs_obs); free(s->partner_obs); free(s->agent_map_obs); free(s->map_obs); free(s->lidar);
+    free(s->bev); free(s->steps_remaining); free(s->shape); free(s->controlled); free(s->resp_type);
+    free(s->trajectory); free(s->world_means); free(s->metadata); free(s->deleted); free(s->map_name);
+    free(s->scenario_id); free(s->agent_id); free(s);
+}
+
+/* Replace world w's Map singleton (mgr.cpp:630-647 / sim.cpp:1000-1001). */
+int orc_set_map(orc_sim *s, int w, const orc_map *m, int clear_deleted) {
+    if (w < 0 || w >= s->W) return -1;
+    World *wd = &s->worlds[w];
+    if (wd->has_map) free_map(&wd->map);
+    copy_map(&wd->map, m);
+    wd->has_map = 1;
+    wd->reset_map = 1;
+    if (clear_deleted) for (int a = 0; a < s->A; a++) s->deleted[(size_t)w * s->A + a] = -1;
+    return 0;
+}
+
+/* mgr.cpp:665-715 */
+int orc_delete_agents(orc_sim *s, int w, const int32_t *ids, int n) {
+    if (w < 0 || w >= s->W || n > s->A) return -1;
+    for (int i = 0; i < n; i++) s->deleted[(size_t)w * s->A + i] = ids[i];
+    s->worlds[w].reset_map = 1;
+    return 0;
+}
+
+static void run_reset_graph(orc_sim *s) { /* sim.cpp:960-966 */
+    int64_t ins = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : ins)
+    for (int w = 0; w < s->W; w++) {
+        reset_system(s, w);
+        rest_of_tasks(s, w, 0, &ins);
+    }
+    s->knn_inserts += ins;
+}
+
+/* Sim::Sim for every world (sim.cpp:973-1012) followed by Manager::reset({}) (mgr.cpp:565). */
+void orc_init(orc_sim *s) {
+    for (int w = 0; w < s->W; w++) {
+        create_persistent_entities(s, w);
+        init_world(s, w);
+    }
+    run_reset_graph(s);
+}
+
+/* mgr.cpp:582-588 */
+void orc_reset(orc_sim *s, const int32_t *worlds, int n) {
+    for (int i = 0; i < n; i++) if (worlds[i] >= 0 && worlds[i] < s->W) s->worlds[worlds[i]].reset_flag = 1;
+    run_reset_graph(s);
+}
+
+/* mgr.cpp:569-580 -> sim.cpp:945-958 */
+void orc_step(orc_sim *s) {
+    int64_t ins = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : ins)
+    for (int w = 0; w < s->W; w++) {
+        World *wd = &s->worlds[w];
+        for (int a = 0; a < wd->num_agents; a++) movement_system(s, w, a);
+        rest_of_tasks(s, w, 1, &ins);
+    }
+    s->knn_inserts += ins;
+}
+
+void *orc_tensor(orc_sim *s, int id) {
+    switch (id) {
+    case T_ACTION: return s->action; case T_REWARD: return s->reward; case T_DONE: return s->done;
+    case T_INFO: return s->info; case T_SELF: return s->self_obs; case T_ABS: return s->abs_obs;
+    case T_PARTNER: return s->partner_obs; case T_AGENT_MAP: return s->agent_map_obs;
+    case T_MAP: return s->map_obs; case T_LIDAR: return s->lidar; case T_BEV: return s->bev;
+    case T_STEPS: return s->steps_remaining; case T_SHAPE: return s->shape;
+    case T_CONTROLLED: return s->controlled; case T_RESP: return s->resp_type;
+    case T_TRAJ: return s->trajectory; case T_MEANS: return s->world_means; case T_META: return s->metadata;
+    case T_DELETED: return s->deleted; case T_MAPNAME: return s->map_name;
+    case T_SCENARIO: return s->scenario_id; case T_AGENT_ID: return s->agent_id;
+    }
+    return NULL;
+}
+
+int64_t orc_knn_inserts(orc_sim *s) { return s->knn_inserts; }
+
+/* Test hooks for teacher forcing: read / overwrite the internal agent state
+ * layout per agent: pos(3) quat wxyz(4) vel_lin(3) collided(1) = 11 floats */
+void orc_get_state(orc_sim *s, float *out) {
+    for (int w = 0; w < s->W; w++)
+        for (int a = 0; a < s->A; a++) {
+            AgentEnt *ag = &s->worlds[w].agents[a];
+            float *o = out + IDX_WA(s, w, a) * 11;
+            if (a >= s->worlds[w].num_agents) { memset(o, 0, 44); continue; }
+            o[0] = ag->pos.x; o[1] = ag->pos.y; o[2] = ag->pos.z;
+            o[3] = ag->rot.w; o[4] = ag->rot.x; o[5] = ag->rot.y; o[6] = ag->rot.z;
+            o[7] = ag->vel_lin.x; o[8] = ag->vel_lin.y; o[9] = ag->vel_lin.z;
+            o[10] = (float)ag->collided;
+        }
+}
+void orc_set_state(orc_sim *s, const float *in) {
+    for (int w = 0; w < s->W; w++)
+        for (int a = 0; a < s->worlds[w].num_agents; a++) {
+            AgentEnt *ag = &s->worlds[w].agents[a];
+            const float *o = in + IDX_WA(s, w, a) * 11;
+            ag->pos.x = o[0]; ag->pos.y = o[1]; ag->pos.z = o[2];
+            ag->rot.w = o[3]; ag->rot.x = o[4]; ag->rot.y = o[5]; ag->rot.z = o[6];
+            ag->vel_lin.x = o[7]; ag->vel_lin.y = o[8]; ag->vel_lin.z = o[9];
+            ag->collided = o[10] != 0.f;
+        }
+}
