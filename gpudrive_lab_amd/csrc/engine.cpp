@@ -1,0 +1,635 @@
+// Host engine + C ABI (include/gpudrive_amd.h).  Citations are relative to the reference checkout.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "gd_math.hpp"
+#include "scene.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(e_));               \
+    } while (0)
+
+struct TensorSpec {
+    int dtype;
+    int ndim;
+    int64_t dims[5];
+};
+
+TensorSpec tensor_spec(int id, int64_t W, int64_t A) {
+    switch (id) {
+    case GD_T_ACTION: return {GD_DTYPE_F32, 3, {W, A, 10}};
+    case GD_T_REWARD: return {GD_DTYPE_F32, 3, {W, A, 1}};
+    case GD_T_DONE: return {GD_DTYPE_I32, 3, {W, A, 1}};
+    case GD_T_INFO: return {GD_DTYPE_I32, 3, {W, A, 5}};
+    case GD_T_SELF_OBS: return {GD_DTYPE_F32, 3, {W, A, 8}};
+    case GD_T_ABS_OBS: return {GD_DTYPE_F32, 3, {W, A, 14}};
+    case GD_T_PARTNER_OBS: return {GD_DTYPE_F32, 4, {W, A, A - 1, 9}};
+    case GD_T_AGENT_MAP_OBS: return {GD_DTYPE_F32, 4, {W, A, GD_MAP_OBS_K, 9}};
+    case GD_T_MAP_OBS: return {GD_DTYPE_F32, 3, {W, GD_MAX_ROAD_ENTITIES, 9}};
+    case GD_T_LIDAR: return {GD_DTYPE_F32, 5, {W, A, 3, GD_NUM_LIDAR_SAMPLES, 4}};
+    case GD_T_BEV: return {GD_DTYPE_F32, 5, {W, A, GD_BEV_RES, GD_BEV_RES, 1}};
+    case GD_T_STEPS_REMAINING: return {GD_DTYPE_I32, 3, {W, A, 1}};
+    case GD_T_SHAPE: return {GD_DTYPE_I32, 2, {W, 2}};
+    case GD_T_CONTROLLED_STATE: return {GD_DTYPE_I32, 3, {W, A, 1}};
+    case GD_T_RESPONSE_TYPE: return {GD_DTYPE_I32, 3, {W, A, 1}};
+    case GD_T_EXPERT_TRAJECTORY: return {GD_DTYPE_F32, 3, {W, A, GD_TRAJECTORY_FLOATS}};
+    case GD_T_WORLD_MEANS: return {GD_DTYPE_F32, 2, {W, 3}};
+    case GD_T_METADATA: return {GD_DTYPE_I32, 3, {W, A, 4}};
+    case GD_T_DELETED_AGENTS: return {GD_DTYPE_I32, 2, {W, A}};
+    case GD_T_MAP_NAME: return {GD_DTYPE_I32, 2, {W, 32}};
+    case GD_T_SCENARIO_ID: return {GD_DTYPE_I32, 2, {W, 32}};
+    }
+    return {-1, 0, {0}};
+}
+
+int64_t spec_bytes(const TensorSpec &s) {
+    int64_t n = 4;
+    for (int i = 0; i < s.ndim; i++) n *= s.dims[i];
+    return n;
+}
+
+struct EventPair {
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct gd_sim {
+    gd_config cfg{};
+    gd_params params{};
+    int W = 0, A = 0;
+    hipStream_t stream = nullptr;
+    gd::DevSim d{};
+    void *exported[GD_T_COUNT] = {};
+    bool owned[GD_T_COUNT] = {};
+    std::vector<void *> internal;
+    std::vector<std::string> scenes;
+    std::vector<int32_t> deleted;  // host mirror [W][A]
+    // per-world host road data (kept to repack the CSR on set_maps / deleteAgents)
+    std::vector<std::vector<float>> w_xy, w_aux;
+    std::vector<std::vector<gd::RoadBox>> w_boxes;
+    size_t road_cap = 0, box_cap = 0;
+    void *d_road_xy = nullptr, *d_road_aux = nullptr, *d_boxes = nullptr;
+    // pinned flag staging ring
+    static constexpr int kRing = 8;
+    int32_t *h_flags[kRing] = {};
+    hipEvent_t flag_ev[kRing] = {};
+    int ring_pos = 0;
+    // kernel timing
+    bool timing = false;
+    std::vector<EventPair> ev_pool[3];
+    size_t ev_used[3] = {0, 0, 0};
+    double ev_ms[3] = {0, 0, 0};
+    int64_t ev_launches[3] = {0, 0, 0};
+
+    ~gd_sim() {
+        if (stream || true) (void)hipDeviceSynchronize();
+        for (int i = 0; i < GD_T_COUNT; i++)
+            if (owned[i] && exported[i]) (void)hipFree(exported[i]);
+        for (void *p : internal) (void)hipFree(p);
+        if (d_road_xy) (void)hipFree(d_road_xy);
+        if (d_road_aux) (void)hipFree(d_road_aux);
+        if (d_boxes) (void)hipFree(d_boxes);
+        for (int i = 0; i < kRing; i++) {
+            if (h_flags[i]) (void)hipHostFree(h_flags[i]);
+            if (flag_ev[i]) (void)hipEventDestroy(flag_ev[i]);
+        }
+        for (auto &pool : ev_pool)
+            for (auto &e : pool) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
+    }
+
+    template <typename T>
+    T *alloc_internal(size_t count) {
+        void *p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+        HIP_CHECK(hipMemset(p, 0, std::max<size_t>(count * sizeof(T), 16)));
+        internal.push_back(p);
+        return static_cast<T *>(p);
+    }
+
+    void collect_timing(int k) {
+        for (size_t i = 0; i < ev_used[k]; i++) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ev_pool[k][i].stop) == hipSuccess &&
+                hipEventElapsedTime(&ms, ev_pool[k][i].start, ev_pool[k][i].stop) == hipSuccess) {
+                ev_ms[k] += ms;
+                ev_launches[k]++;
+            }
+        }
+        ev_used[k] = 0;
+    }
+
+    void launch(int which, bool move) {
+        const bool timed = timing && which <= gd::KERNEL_PARTNER;
+        EventPair ep{};
+        if (timed) {
+            if (ev_used[which] == ev_pool[which].size()) {
+                if (ev_pool[which].size() >= 4096) collect_timing(which);
+                if (ev_used[which] == ev_pool[which].size()) {
+                    EventPair n{};
+                    HIP_CHECK(hipEventCreate(&n.start));
+                    HIP_CHECK(hipEventCreate(&n.stop));
+                    ev_pool[which].push_back(n);
+                }
+            }
+            ep = ev_pool[which][ev_used[which]++];
+            HIP_CHECK(hipEventRecord(ep.start, stream));
+        }
+        gd::launch_kernel(d, stream, which, move);
+        if (timed) HIP_CHECK(hipEventRecord(ep.stop, stream));
+        HIP_CHECK(hipGetLastError());
+    }
+
+    // setupRestOfTasks, src/sim.cpp:785-943
+    void run_rest(bool move) {
+        launch(gd::KERNEL_STATE, move);
+        if (!params.disableClassicalObs) launch(gd::KERNEL_MAP_OBS, move);
+    }
+
+    void upload_flags(int32_t *dst, const std::vector<int32_t> &flags) {
+        const int slot = ring_pos;
+        ring_pos = (ring_pos + 1) % kRing;
+        HIP_CHECK(hipEventSynchronize(flag_ev[slot]));
+        std::memcpy(h_flags[slot], flags.data(), sizeof(int32_t) * W);
+        HIP_CHECK(hipMemcpyAsync(dst, h_flags[slot], sizeof(int32_t) * W, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipEventRecord(flag_ev[slot], stream));
+    }
+
+    // (Re)build the listed worlds on the host and upload their init-time rows:
+    // MapReader::parseAndWriteOut + createPersistentEntities (src/mgr.cpp:527-535,630-647;
+    // src/level_gen.cpp:396-465).
+    void rebuild_worlds(const std::vector<int> &worlds) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        std::map<std::string, std::shared_ptr<const gd::SceneMap>> scene_cache;
+        std::map<std::string, std::shared_ptr<gd::HostWorld>> world_cache;
+        std::vector<float> map_rows(static_cast<size_t>(GD_MAX_ROAD_ENTITIES) * 9);
+        std::vector<int32_t> rebuilt(W, 0);
+        for (int w : worlds) {
+            const std::string &path = scenes[w];
+            const int32_t *del = deleted.data() + static_cast<size_t>(w) * A;
+            int ndel = 0;
+            std::string key = path;
+            for (int i = 0; i < A; i++)
+                if (del[i] != -1) { ndel = i + 1; }
+            for (int i = 0; i < ndel; i++) key += "|" + std::to_string(del[i]);
+            std::shared_ptr<gd::HostWorld> hw;
+            auto it = world_cache.find(key);
+            if (it != world_cache.end()) {
+                hw = it->second;
+            } else {
+                auto sit = scene_cache.find(path);
+                if (sit == scene_cache.end())
+                    sit = scene_cache.emplace(path, gd::parse_scene_file(path, params.polylineReductionThreshold)).first;
+                hw = std::make_shared<gd::HostWorld>();
+                gd::build_host_world(*sit->second, params, A, del, ndel, *hw);
+                world_cache.emplace(key, hw);
+            }
+            const size_t o = static_cast<size_t>(w) * A;
+            auto up = [&](void *dst, const void *src, size_t bytes) {
+                HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+            };
+            up(d.traj + o * GD_TRAJECTORY_FLOATS, hw->trajectory.data(), sizeof(float) * A * GD_TRAJECTORY_FLOATS);
+            // split SoA planes
+            std::vector<float> tmp(A);
+            auto up_col = [&](float *dst, const std::vector<float> &src, int stride, int col) {
+                for (int a = 0; a < A; a++) tmp[a] = src[static_cast<size_t>(a) * stride + col];
+                up(dst + o, tmp.data(), sizeof(float) * A);
+            };
+            up_col(d.len, hw->size, 3, 0);
+            up_col(d.wid, hw->size, 3, 1);
+            up_col(d.hgt, hw->size, 3, 2);
+            up_col(d.sc0, hw->scale, 2, 0);
+            up_col(d.sc1, hw->scale, 2, 1);
+            up_col(d.goal_x, hw->goal, 2, 0);
+            up_col(d.goal_y, hw->goal, 2, 1);
+            up(d.etype + o, hw->etype.data(), sizeof(int32_t) * A);
+            up(d.agent_id + o, hw->agent_id.data(), sizeof(int32_t) * A);
+            up(d.resp + o, hw->resp.data(), sizeof(int32_t) * A);
+            up(d.controlled + o, hw->controlled.data(), sizeof(int32_t) * A);
+            up(d.metadata + o * 4, hw->metadata.data(), sizeof(int32_t) * A * 4);
+            up(d.deleted + o, del, sizeof(int32_t) * A);
+            up(d.means + static_cast<size_t>(w) * 3, hw->mean, sizeof(float) * 3);
+            up(d.map_name + static_cast<size_t>(w) * 32, hw->map_name, sizeof(int32_t) * 32);
+            up(d.scenario_id + static_cast<size_t>(w) * 32, hw->scenario_id, sizeof(int32_t) * 32);
+            const int32_t shape[2] = {hw->num_agents, hw->num_roads};
+            up(d.shape + static_cast<size_t>(w) * 2, shape, sizeof(shape));
+            // map_observation_tensor rows + MapObservation::zero() padding (src/level_gen.cpp:331-335)
+            std::memcpy(map_rows.data(), hw->map_obs.data(), sizeof(float) * hw->map_obs.size());
+            for (int r = hw->num_roads; r < GD_MAX_ROAD_ENTITIES; r++) {
+                float *row = map_rows.data() + static_cast<size_t>(r) * 9;
+                for (int c = 0; c < 7; c++) row[c] = 0.f;
+                row[7] = -1.f;
+                row[8] = -1.f;
+            }
+            up(d.map_obs + static_cast<size_t>(w) * GD_MAX_ROAD_ENTITIES * 9, map_rows.data(),
+               sizeof(float) * map_rows.size());
+            w_xy[w] = hw->road_xy;
+            w_aux[w] = hw->road_aux;
+            w_boxes[w] = hw->boxes;
+            rebuilt[w] = 1;
+        }
+        // repack the road CSR
+        std::vector<int32_t> road_off(W + 1, 0), box_off(W + 1, 0);
+        for (int w = 0; w < W; w++) {
+            road_off[w + 1] = road_off[w] + static_cast<int32_t>(w_xy[w].size() / 2);
+            box_off[w + 1] = box_off[w] + static_cast<int32_t>(w_boxes[w].size());
+        }
+        const size_t nroad = road_off[W], nbox = box_off[W];
+        if (nroad > road_cap) {
+            if (d_road_xy) (void)hipFree(d_road_xy);
+            if (d_road_aux) (void)hipFree(d_road_aux);
+            road_cap = nroad + nroad / 8 + 64;
+            HIP_CHECK(hipMalloc(&d_road_xy, road_cap * sizeof(float) * 2));
+            HIP_CHECK(hipMalloc(&d_road_aux, road_cap * sizeof(float) * 8));
+        }
+        if (nbox > box_cap) {
+            if (d_boxes) (void)hipFree(d_boxes);
+            box_cap = nbox + nbox / 8 + 64;
+            HIP_CHECK(hipMalloc(&d_boxes, box_cap * sizeof(gd::RoadBox)));
+        }
+        {
+            std::vector<float> xy(nroad * 2), aux(nroad * 8);
+            std::vector<gd::RoadBox> boxes(nbox);
+            for (int w = 0; w < W; w++) {
+                std::copy(w_xy[w].begin(), w_xy[w].end(), xy.begin() + static_cast<size_t>(road_off[w]) * 2);
+                std::copy(w_aux[w].begin(), w_aux[w].end(), aux.begin() + static_cast<size_t>(road_off[w]) * 8);
+                std::copy(w_boxes[w].begin(), w_boxes[w].end(), boxes.begin() + box_off[w]);
+            }
+            if (nroad) {
+                HIP_CHECK(hipMemcpy(d_road_xy, xy.data(), xy.size() * sizeof(float), hipMemcpyHostToDevice));
+                HIP_CHECK(hipMemcpy(d_road_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            if (nbox) HIP_CHECK(hipMemcpy(d_boxes, boxes.data(), nbox * sizeof(gd::RoadBox), hipMemcpyHostToDevice));
+        }
+        HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.road_off), road_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.box_off), box_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
+        d.road_xy = static_cast<const float2 *>(d_road_xy);
+        d.road_aux = static_cast<const float4 *>(d_road_aux);
+        d.boxes = static_cast<const float4 *>(d_boxes);
+        HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
+        launch(gd::KERNEL_PADDING, false);
+    }
+
+    void do_reset(const std::vector<int32_t> &flags) {
+        upload_flags(d.reset_flags, flags);
+        launch(gd::KERNEL_RESET, false);
+        run_rest(false);
+    }
+};
+
+namespace {
+
+template <typename F>
+int guarded(F &&f) {
+    try {
+        f();
+        return GD_OK;
+    } catch (const HipError &e) {
+        return fail(GD_ERR_DEVICE, e.what());
+    } catch (const std::invalid_argument &e) {
+        const std::string m = e.what();
+        return fail(m.find("cannot open") != std::string::npos ? GD_ERR_IO : GD_ERR_INVALID, m);
+    } catch (const std::exception &e) {
+        return fail(GD_ERR_PARSE, e.what());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gd_version(void) { return "gpudrive_amd 0.1 (gfx950)"; }
+const char *gd_last_error(void) { return g_last_error.c_str(); }
+
+void gd_default_params(gd_params *p) {  // src/init.hpp:111-127
+    std::memset(p, 0, sizeof(*p));
+    p->collisionBehaviour = GD_COLLISION_AGENT_STOP;
+    p->maxNumControlledAgents = 10000;
+    p->IgnoreNonVehicles = 0;
+    p->roadObservationAlgorithm = GD_ROADS_K_NEAREST;
+    p->initOnlyValidAgentsAtFirstStep = 1;
+    p->isStaticAgentControlled = 0;
+    p->dynamicsModel = GD_DYNAMICS_CLASSIC;
+}
+
+int gd_tensor_shape(int32_t id, int32_t W, int32_t A, gd_tensor_desc *out) {
+    if (!out || id < 0 || id >= GD_T_COUNT || W < 1 || A < 2) return fail(GD_ERR_INVALID, "gd_tensor_shape: bad argument");
+    const TensorSpec s = tensor_spec(id, W, A);
+    out->data = nullptr;
+    out->dtype = s.dtype;
+    out->ndim = s.ndim;
+    for (int i = 0; i < 5; i++) out->dims[i] = i < s.ndim ? s.dims[i] : 1;
+    out->nbytes = spec_bytes(s);
+    return GD_OK;
+}
+
+int gd_create(const gd_config *cfg, const gd_params *params, const char *const *scenes, gd_sim **out) {
+    if (!cfg || !params || !scenes || !out) return fail(GD_ERR_INVALID, "gd_create: null argument");
+    if (cfg->num_worlds < 1) return fail(GD_ERR_INVALID, "gd_create: num_worlds must be >= 1");
+    if (cfg->max_agents != 64 && cfg->max_agents != 128)
+        return fail(GD_ERR_INVALID, "gd_create: max_agents must be 64 or 128");
+    if (params->rewardType == GD_REWARD_DENSE)
+        return fail(GD_ERR_UNSUPPORTED, "RewardType::Dense is assert(false) in the reference (src/sim.cpp:579-583)");
+    *out = nullptr;
+    std::unique_ptr<gd_sim> s(new gd_sim());
+    const int rc = guarded([&]() {
+        int ndev = 0;
+        HIP_CHECK(hipGetDeviceCount(&ndev));
+        if (ndev < 1) throw HipError("no HIP device visible: the HIP path is mandatory, there is no CPU fallback");
+        HIP_CHECK(hipSetDevice(cfg->device_id));
+        s->cfg = *cfg;
+        s->params = *params;
+        s->W = cfg->num_worlds;
+        s->A = cfg->max_agents;
+        s->stream = static_cast<hipStream_t>(cfg->stream);
+        const int W = s->W, A = s->A;
+        for (int w = 0; w < W; w++) {
+            if (!scenes[w]) throw std::invalid_argument("gd_create: null scene path");
+            s->scenes.emplace_back(scenes[w]);
+        }
+        s->deleted.assign(static_cast<size_t>(W) * A, -1);  // src/sim.cpp:1003-1006
+        s->w_xy.resize(W);
+        s->w_aux.resize(W);
+        s->w_boxes.resize(W);
+        for (int id = 0; id < GD_T_COUNT; id++) {
+            if (id == GD_T_BEV && !cfg->alloc_bev && !cfg->external[id]) continue;
+            const int64_t bytes = spec_bytes(tensor_spec(id, W, A));
+            if (cfg->external[id]) {
+                s->exported[id] = cfg->external[id];
+            } else {
+                HIP_CHECK(hipMalloc(&s->exported[id], bytes));
+                s->owned[id] = true;
+            }
+            HIP_CHECK(hipMemset(s->exported[id], 0, bytes));
+        }
+        gd::DevSim &d = s->d;
+        d.W = W;
+        d.A = A;
+        d.p = *params;
+        d.action = static_cast<float *>(s->exported[GD_T_ACTION]);
+        d.reward = static_cast<float *>(s->exported[GD_T_REWARD]);
+        d.done = static_cast<int32_t *>(s->exported[GD_T_DONE]);
+        d.info = static_cast<int32_t *>(s->exported[GD_T_INFO]);
+        d.self_obs = static_cast<float *>(s->exported[GD_T_SELF_OBS]);
+        d.abs_obs = static_cast<float *>(s->exported[GD_T_ABS_OBS]);
+        d.partner = static_cast<float *>(s->exported[GD_T_PARTNER_OBS]);
+        d.agent_map = static_cast<float *>(s->exported[GD_T_AGENT_MAP_OBS]);
+        d.map_obs = static_cast<float *>(s->exported[GD_T_MAP_OBS]);
+        d.lidar = static_cast<float *>(s->exported[GD_T_LIDAR]);
+        d.bev = static_cast<float *>(s->exported[GD_T_BEV]);
+        d.steps = static_cast<uint32_t *>(s->exported[GD_T_STEPS_REMAINING]);
+        d.shape = static_cast<int32_t *>(s->exported[GD_T_SHAPE]);
+        d.controlled = static_cast<int32_t *>(s->exported[GD_T_CONTROLLED_STATE]);
+        d.resp_export = static_cast<int32_t *>(s->exported[GD_T_RESPONSE_TYPE]);
+        d.traj = static_cast<float *>(s->exported[GD_T_EXPERT_TRAJECTORY]);
+        d.means = static_cast<float *>(s->exported[GD_T_WORLD_MEANS]);
+        d.metadata = static_cast<int32_t *>(s->exported[GD_T_METADATA]);
+        d.deleted = static_cast<int32_t *>(s->exported[GD_T_DELETED_AGENTS]);
+        d.map_name = static_cast<int32_t *>(s->exported[GD_T_MAP_NAME]);
+        d.scenario_id = static_cast<int32_t *>(s->exported[GD_T_SCENARIO_ID]);
+        const size_t WA = static_cast<size_t>(W) * A;
+        d.px = s->alloc_internal<float>(WA); d.py = s->alloc_internal<float>(WA); d.pz = s->alloc_internal<float>(WA);
+        d.qw = s->alloc_internal<float>(WA); d.qz = s->alloc_internal<float>(WA);
+        d.vx = s->alloc_internal<float>(WA); d.vy = s->alloc_internal<float>(WA); d.vz = s->alloc_internal<float>(WA);
+        d.collided = s->alloc_internal<int32_t>(WA);
+        d.len = s->alloc_internal<float>(WA); d.wid = s->alloc_internal<float>(WA); d.hgt = s->alloc_internal<float>(WA);
+        d.sc0 = s->alloc_internal<float>(WA); d.sc1 = s->alloc_internal<float>(WA);
+        d.goal_x = s->alloc_internal<float>(WA); d.goal_y = s->alloc_internal<float>(WA);
+        d.etype = s->alloc_internal<int32_t>(WA); d.agent_id = s->alloc_internal<int32_t>(WA);
+        d.resp = s->alloc_internal<int32_t>(WA);
+        d.reset_flags = s->alloc_internal<int32_t>(W);
+        d.rebuilt_flags = s->alloc_internal<int32_t>(W);
+        d.road_off = s->alloc_internal<int32_t>(W + 1);
+        d.box_off = s->alloc_internal<int32_t>(W + 1);
+        for (int i = 0; i < gd_sim::kRing; i++) {
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->h_flags[i]), sizeof(int32_t) * W, hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&s->flag_ev[i], hipEventDisableTiming));
+        }
+        std::vector<int> all(W);
+        for (int w = 0; w < W; w++) all[w] = w;
+        s->rebuild_worlds(all);
+        // Sim::Sim -> initWorld for every world, then Manager::reset({}) (src/sim.cpp:1008-1011, src/mgr.cpp:565)
+        s->do_reset(std::vector<int32_t>(W, 1));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+    });
+    if (rc != GD_OK) return rc;
+    *out = s.release();
+    return GD_OK;
+}
+
+void gd_destroy(gd_sim *sim) { delete sim; }
+
+int gd_step(gd_sim *s) {
+    if (!s) return fail(GD_ERR_INVALID, "gd_step: null sim");
+    return guarded([&]() { s->run_rest(true); });
+}
+
+int gd_reset(gd_sim *s, const int32_t *idx, int32_t n) {
+    if (!s || (n > 0 && !idx)) return fail(GD_ERR_INVALID, "gd_reset: bad argument");
+    std::vector<int32_t> flags(s->W, 0);
+    for (int i = 0; i < n; i++) {
+        if (idx[i] < 0 || idx[i] >= s->W) return fail(GD_ERR_INVALID, "gd_reset: world index out of range");
+        flags[idx[i]] = 1;
+    }
+    return guarded([&]() { s->do_reset(flags); });
+}
+
+int gd_set_maps(gd_sim *s, const char *const *scenes, int32_t n) {
+    if (!s || !scenes) return fail(GD_ERR_INVALID, "gd_set_maps: null argument");
+    if (n != s->W) return fail(GD_ERR_INVALID, "gd_set_maps: len(maps) must equal the number of worlds");
+    const std::vector<std::string> old_scenes = s->scenes;
+    const std::vector<int32_t> old_deleted = s->deleted;
+    const int rc = guarded([&]() {
+        for (int w = 0; w < n; w++) {
+            if (!scenes[w]) throw std::invalid_argument("gd_set_maps: null scene path");
+            s->scenes[w] = scenes[w];
+        }
+        std::fill(s->deleted.begin(), s->deleted.end(), -1);  // src/mgr.cpp:613-617
+        std::vector<int> all(s->W);
+        for (int w = 0; w < s->W; w++) all[w] = w;
+        s->rebuild_worlds(all);
+        s->do_reset(std::vector<int32_t>(s->W, 1));
+    });
+    if (rc != GD_OK && rc != GD_ERR_DEVICE) {  // leave the previous worlds in place on a bad file
+        s->scenes = old_scenes;
+        s->deleted = old_deleted;
+    }
+    return rc;
+}
+
+int gd_delete_agents(gd_sim *s, const int32_t *worlds, const int32_t *offsets, const int32_t *ids, int32_t nw) {
+    if (!s || (nw > 0 && (!worlds || !offsets))) return fail(GD_ERR_INVALID, "gd_delete_agents: null argument");
+    std::vector<int> touched;
+    for (int i = 0; i < nw; i++) {
+        const int w = worlds[i], cnt = offsets[i + 1] - offsets[i];
+        if (w < 0 || w >= s->W) return fail(GD_ERR_INVALID, "gd_delete_agents: world index out of range");
+        if (cnt < 0 || cnt > s->A) return fail(GD_ERR_INVALID, "gd_delete_agents: too many ids for one world");
+    }
+    return guarded([&]() {
+        for (int i = 0; i < nw; i++) {
+            const int w = worlds[i], cnt = offsets[i + 1] - offsets[i];
+            for (int k = 0; k < cnt; k++) s->deleted[static_cast<size_t>(w) * s->A + k] = ids[offsets[i] + k];
+            touched.push_back(w);
+        }
+        s->rebuild_worlds(touched);
+        s->do_reset(std::vector<int32_t>(s->W, 1));  // src/mgr.cpp:712-714: reset(all)
+    });
+}
+
+int gd_tensor(gd_sim *s, int32_t id, gd_tensor_desc *out) {
+    if (!s || !out || id < 0 || id >= GD_T_COUNT) return fail(GD_ERR_INVALID, "gd_tensor: bad argument");
+    if (!s->exported[id]) return fail(GD_ERR_UNSUPPORTED, "tensor not allocated (set gd_config.alloc_bev for the BEV tensor)");
+    gd_tensor_shape(id, s->W, s->A, out);
+    out->data = s->exported[id];
+    return GD_OK;
+}
+
+int gd_sync(gd_sim *s) {
+    if (!s) return fail(GD_ERR_INVALID, "gd_sync: null sim");
+    return guarded([&]() { HIP_CHECK(hipStreamSynchronize(s->stream)); });
+}
+
+int gd_set_stream(gd_sim *s, void *stream) {
+    if (!s) return fail(GD_ERR_INVALID, "gd_set_stream: null sim");
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->stream = static_cast<hipStream_t>(stream);
+    });
+}
+
+int gd_kernel_timing_enable(gd_sim *s, int32_t enable) {
+    if (!s) return fail(GD_ERR_INVALID, "null sim");
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        for (int k = 0; k < 3; k++) {
+            s->collect_timing(k);
+            s->ev_ms[k] = 0;
+            s->ev_launches[k] = 0;
+        }
+        s->timing = enable != 0;
+    });
+}
+
+int gd_kernel_timing_read(gd_sim *s, int32_t kernel, double *total_ms, int64_t *launches) {
+    if (!s || kernel < 0 || kernel > 2) return fail(GD_ERR_INVALID, "gd_kernel_timing_read: bad argument");
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->collect_timing(kernel);
+        if (total_ms) *total_ms = s->ev_ms[kernel];
+        if (launches) *launches = s->ev_launches[kernel];
+    });
+}
+
+int gd_debug_get_state(gd_sim *s, float *out) {
+    if (!s || !out) return fail(GD_ERR_INVALID, "null argument");
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        const size_t WA = static_cast<size_t>(s->W) * s->A;
+        std::vector<float> plane(WA);
+        std::vector<int32_t> iplane(WA);
+        const float *src[8] = {s->d.px, s->d.py, s->d.pz, s->d.qw, s->d.qz, s->d.vx, s->d.vy, s->d.vz};
+        const int dstcol[8] = {0, 1, 2, 3, 6, 7, 8, 9};
+        for (size_t i = 0; i < WA * 11; i++) out[i] = 0.f;
+        for (int k = 0; k < 8; k++) {
+            HIP_CHECK(hipMemcpy(plane.data(), src[k], WA * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < WA; i++) out[i * 11 + dstcol[k]] = plane[i];
+        }
+        for (size_t i = 0; i < WA; i++) {  // x, y = 0 * z as produced by angleAxis
+            out[i * 11 + 4] = 0.f * out[i * 11 + 6];
+            out[i * 11 + 5] = 0.f * out[i * 11 + 6];
+        }
+        HIP_CHECK(hipMemcpy(iplane.data(), s->d.collided, WA * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < WA; i++) out[i * 11 + 10] = static_cast<float>(iplane[i]);
+    });
+}
+
+int gd_debug_set_state(gd_sim *s, const float *in) {
+    if (!s || !in) return fail(GD_ERR_INVALID, "null argument");
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        const size_t WA = static_cast<size_t>(s->W) * s->A;
+        std::vector<float> plane(WA);
+        std::vector<int32_t> iplane(WA);
+        float *dst[8] = {s->d.px, s->d.py, s->d.pz, s->d.qw, s->d.qz, s->d.vx, s->d.vy, s->d.vz};
+        const int srccol[8] = {0, 1, 2, 3, 6, 7, 8, 9};
+        for (int k = 0; k < 8; k++) {
+            for (size_t i = 0; i < WA; i++) plane[i] = in[i * 11 + srccol[k]];
+            HIP_CHECK(hipMemcpy(dst[k], plane.data(), WA * 4, hipMemcpyHostToDevice));
+        }
+        for (size_t i = 0; i < WA; i++) iplane[i] = in[i * 11 + 10] != 0.f;
+        HIP_CHECK(hipMemcpy(s->d.collided, iplane.data(), WA * 4, hipMemcpyHostToDevice));
+    });
+}
+
+int gd_host_world_build(const char *scene, const gd_params *params, int32_t A, const int32_t *deleted, int32_t ndel,
+                        gd_host_world *out) {
+    if (!scene || !params || !out || A < 2 || A > GD_MAX_AGENTS_LIMIT) return fail(GD_ERR_INVALID, "gd_host_world_build: bad argument");
+    std::memset(out, 0, sizeof(*out));
+    return guarded([&]() {
+        auto map = gd::parse_scene_file(scene, params->polylineReductionThreshold);
+        gd::HostWorld hw;
+        gd::build_host_world(*map, *params, A, deleted, ndel, hw);
+        out->num_agents = hw.num_agents;
+        out->num_roads = hw.num_roads;
+        out->num_collidable_roads = static_cast<int32_t>(hw.boxes.size());
+        out->max_agents = A;
+        std::memcpy(out->mean, hw.mean, sizeof(hw.mean));
+        std::memcpy(out->map_name, hw.map_name, sizeof(hw.map_name));
+        std::memcpy(out->scenario_id, hw.scenario_id, sizeof(hw.scenario_id));
+        auto dupf = [](const std::vector<float> &v, size_t n) {
+            float *p = static_cast<float *>(std::calloc(std::max<size_t>(n, 1), sizeof(float)));
+            std::memcpy(p, v.data(), std::min(n, v.size()) * sizeof(float));
+            return p;
+        };
+        auto dupi = [](const std::vector<int32_t> &v) {
+            int32_t *p = static_cast<int32_t *>(std::calloc(std::max<size_t>(v.size(), 1), sizeof(int32_t)));
+            std::memcpy(p, v.data(), v.size() * sizeof(int32_t));
+            return p;
+        };
+        out->map_obs = dupf(hw.map_obs, static_cast<size_t>(GD_MAX_ROAD_ENTITIES) * 9);
+        for (int r = hw.num_roads; r < GD_MAX_ROAD_ENTITIES; r++) { out->map_obs[r * 9 + 7] = -1.f; out->map_obs[r * 9 + 8] = -1.f; }
+        out->trajectory = dupf(hw.trajectory, hw.trajectory.size());
+        out->vehicle_size = dupf(hw.size, hw.size.size());
+        out->goal = dupf(hw.goal, hw.goal.size());
+        out->controlled = dupi(hw.controlled);
+        out->response_type = dupi(hw.resp);
+        out->agent_id = dupi(hw.agent_id);
+        out->entity_type = dupi(hw.etype);
+        out->metadata = dupi(hw.metadata);
+    });
+}
+
+void gd_host_world_free(gd_host_world *w) {
+    if (!w) return;
+    std::free(w->map_obs); std::free(w->trajectory); std::free(w->vehicle_size); std::free(w->goal);
+    std::free(w->controlled); std::free(w->response_type); std::free(w->agent_id); std::free(w->entity_type);
+    std::free(w->metadata);
+    std::memset(w, 0, sizeof(*w));
+}
+
+}  // extern "C"

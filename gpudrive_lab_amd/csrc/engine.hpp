@@ -1,0 +1,43 @@
+// Device-side view of one simulator instance, shared between the host engine and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/gpudrive_amd.h"
+
+namespace gd {
+
+enum { KERNEL_STATE = 0, KERNEL_MAP_OBS = 1, KERNEL_PARTNER = 2, KERNEL_RESET = 3, KERNEL_PADDING = 4 };
+
+// Passed to kernels by value.  HBM layout:
+//   exported tensors : the reference's AoS layouts (API contract, src/mgr.cpp:656-902)
+//   agent state      : world-major SoA, one [W][A] plane per field
+//   roads            : CSR over worlds; (x,y) float2 stream for the scan, 2 x float4 per road
+//                      {qw,qz,d0,d1 | d2,type,id,mapType} gathered only for selected rows
+//   collidable boxes : CSR over worlds; 5 x float4 per box {cx,cy,radius,type | 14-float OBB}
+struct DevSim {
+    int W, A;
+    gd_params p;
+    // exported
+    float *action, *reward, *self_obs, *abs_obs, *partner, *agent_map, *map_obs, *lidar, *bev, *traj, *means;
+    int32_t *done, *info, *shape, *controlled, *resp_export, *metadata, *deleted, *map_name, *scenario_id;
+    uint32_t *steps;
+    // internal agent state [W][A]
+    float *px, *py, *pz, *qw, *qz, *vx, *vy, *vz;
+    int32_t *collided;
+    float *len, *wid, *hgt, *sc0, *sc1, *goal_x, *goal_y;
+    int32_t *etype, *agent_id, *resp;
+    // per world flags
+    int32_t *reset_flags, *rebuilt_flags;
+    // roads
+    const int32_t *road_off;  // [W+1]
+    const float2 *road_xy;
+    const float4 *road_aux;
+    const int32_t *box_off;   // [W+1]
+    const float4 *boxes;
+};
+
+void launch_kernel(const DevSim &d, hipStream_t st, int which, bool move);
+
+}  // namespace gd

@@ -1,0 +1,189 @@
+/*
+ * gpudrive_amd.h -- C ABI of the MI355X-native GPUDrive step engine (libgpudrive_amd.so).
+ *
+ * This is the drop-in boundary for ONE path of CILAB-MA/gpudrive_lab: the batched per-world
+ * simulation step behind `madrona_gpudrive.SimManager`.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference checkout).  Plain pointers and sizes
+ * only; no torch / Python types.  All functions return GD_OK (0) or a negative error code and
+ * never abort the process; gd_last_error() returns the message of the calling thread's last
+ * failure.
+ *
+ * Buffers: every exported tensor lives in device (HBM) memory for the lifetime of the sim.
+ * Either the caller hands in device pointers (gd_config.external[...], e.g. torch-allocated
+ * storage so that `.to_torch()` is a zero-copy alias) or the engine allocates them itself.
+ * The exported buffers ARE the live simulation storage, exactly like Madrona's exported ECS
+ * columns: actions are written in place by the caller (gpudrive/env/env_torch.py:645-664) and
+ * `controlled_state`, `done`, `expert_trajectory` ... are read back by the next step.
+ */
+#ifndef GPUDRIVE_AMD_H
+#define GPUDRIVE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GD_OK 0
+#define GD_ERR_INVALID (-1)   /* bad argument */
+#define GD_ERR_IO (-2)        /* scene file missing / unreadable (reference: assert, src/MapReader.cpp:40) */
+#define GD_ERR_PARSE (-3)     /* malformed scene JSON (reference: nlohmann exception -> abort) */
+#define GD_ERR_DEVICE (-4)    /* HIP runtime failure, no gfx950 device */
+#define GD_ERR_UNSUPPORTED (-5)
+
+/* src/consts.hpp:11-13,34,37 */
+#define GD_MAX_AGENTS_LIMIT 128
+#define GD_MAX_ROAD_ENTITIES 10000
+#define GD_MAP_OBS_K 200
+#define GD_EPISODE_LEN 91
+#define GD_NUM_LIDAR_SAMPLES 50
+#define GD_TRAJECTORY_FLOATS 1456   /* src/types.hpp:373 */
+#define GD_BEV_RES 200
+#define GD_VEHICLE_SCALE 0.7f       /* src/consts.hpp:25 */
+
+/* src/init.hpp:76-109 enums (values as seen through src/bindings.cpp:31-88) */
+enum { GD_REWARD_DISTANCE_BASED = 0, GD_REWARD_ON_GOAL_ACHIEVED = 1, GD_REWARD_DENSE = 2 };
+enum { GD_COLLISION_AGENT_STOP = 0, GD_COLLISION_AGENT_REMOVED = 1, GD_COLLISION_IGNORE = 2 };
+enum { GD_DYNAMICS_CLASSIC = 0, GD_DYNAMICS_INVERTIBLE_BICYCLE = 1, GD_DYNAMICS_DELTA_LOCAL = 2,
+       GD_DYNAMICS_STATE = 3 };
+enum { GD_ROADS_K_NEAREST = 0, GD_ROADS_ALL_WITHIN_RADIUS = 1 };
+
+/* src/init.hpp:111-127 `Parameters` (+ RewardParams :83-88), field for field. */
+typedef struct gd_params {
+    float polylineReductionThreshold;
+    float observationRadius;
+    int32_t rewardType;
+    float distanceToGoalThreshold;
+    float distanceToExpertThreshold;
+    int32_t collisionBehaviour;          /* default AgentStop */
+    uint32_t maxNumControlledAgents;     /* default 10000 */
+    int32_t IgnoreNonVehicles;           /* default 0 */
+    int32_t roadObservationAlgorithm;    /* default K nearest */
+    int32_t initOnlyValidAgentsAtFirstStep; /* default 1 */
+    int32_t isStaticAgentControlled;     /* default 0 */
+    int32_t enableLidar;                 /* default 0 */
+    int32_t disableClassicalObs;         /* default 0 */
+    int32_t dynamicsModel;               /* default Classic */
+    int32_t readFromTracksToPredict;     /* default 0 */
+} gd_params;
+
+/* Export slots: src/sim.hpp:17-45 `ExportID`, in the order of the getters of src/bindings.cpp:109-149. */
+enum {
+    GD_T_ACTION = 0,          /* action_tensor                   f32 [W,A,10]        mgr.cpp:718 */
+    GD_T_REWARD,              /* reward_tensor                   f32 [W,A,1]         mgr.cpp:729 */
+    GD_T_DONE,                /* done_tensor                     i32 [W,A,1]         mgr.cpp:749 */
+    GD_T_INFO,                /* info_tensor                     i32 [W,A,5]         mgr.cpp:759 */
+    GD_T_SELF_OBS,            /* self_observation_tensor         f32 [W,A,8]         mgr.cpp:769 */
+    GD_T_ABS_OBS,             /* absolute_self_observation_tensor f32 [W,A,14]       mgr.cpp:865 */
+    GD_T_PARTNER_OBS,         /* partner_observations_tensor     f32 [W,A,A-1,9]     mgr.cpp:792 */
+    GD_T_AGENT_MAP_OBS,       /* agent_roadmap_tensor            f32 [W,A,200,9]     mgr.cpp:804 */
+    GD_T_MAP_OBS,             /* map_observation_tensor          f32 [W,10000,9]     mgr.cpp:780 */
+    GD_T_LIDAR,               /* lidar_tensor                    f32 [W,A,3,50,4]    mgr.cpp:817 */
+    GD_T_BEV,                 /* bev_observation_tensor          f32 [W,A,200,200,1] mgr.cpp:829 (lazy) */
+    GD_T_STEPS_REMAINING,     /* steps_remaining_tensor          i32 [W,A,1]         mgr.cpp:841 */
+    GD_T_SHAPE,               /* shape_tensor                    i32 [W,2]           mgr.cpp:852 */
+    GD_T_CONTROLLED_STATE,    /* controlled_state_tensor         i32 [W,A,1]         mgr.cpp:857 */
+    GD_T_RESPONSE_TYPE,       /* response_type_tensor            i32 [W,A,1]         mgr.cpp:861 */
+    GD_T_EXPERT_TRAJECTORY,   /* expert_trajectory_tensor        f32 [W,A,1456]      mgr.cpp:877 */
+    GD_T_WORLD_MEANS,         /* world_means_tensor              f32 [W,3]           mgr.cpp:739 */
+    GD_T_METADATA,            /* metadata_tensor                 i32 [W,A,4]         mgr.cpp:897 */
+    GD_T_DELETED_AGENTS,      /* deleted_agents_tensor           i32 [W,A]           mgr.cpp:656 */
+    GD_T_MAP_NAME,            /* map_name_tensor                 i32 [W,32]          mgr.cpp:883 */
+    GD_T_SCENARIO_ID,         /* scenario_id_tensor              i32 [W,32]          mgr.cpp:890 */
+    GD_T_COUNT
+};
+
+enum { GD_DTYPE_F32 = 0, GD_DTYPE_I32 = 1 };
+
+typedef struct gd_tensor_desc {
+    void *data;        /* device pointer (NULL from gd_tensor_shape) */
+    int32_t dtype;     /* GD_DTYPE_* */
+    int32_t ndim;
+    int64_t dims[5];
+    int64_t nbytes;
+} gd_tensor_desc;
+
+/* How the k-NN road observation orders its rows. */
+enum {
+    GD_KNN_REFERENCE_ORDER = 0, /* rows in the reference's SGI-heap array order (src/knn.hpp:103-158) */
+    GD_KNN_SET_ORDER = 1        /* same row SET, ascending road index; NOT elementwise identical */
+};
+
+/* Manager::Config (src/mgr.hpp:30-44) minus the render fields, plus engine knobs. */
+typedef struct gd_config {
+    int32_t num_worlds;         /* = len(scenes) */
+    int32_t max_agents;         /* consts::kMaxAgentCount: 64 (benchmark configs) or 128 (this fork) */
+    int32_t device_id;          /* Config::gpuID */
+    void *stream;               /* hipStream_t to launch on; NULL = the null stream */
+    int32_t knn_order;          /* GD_KNN_* */
+    int32_t alloc_bev;          /* 1: allocate + compute the BEV tensor (160 KB/agent) */
+    float lidar_half_angle;     /* consts::lidarAngle; 0 -> pi/3 (reference), pi -> 360 degrees */
+    void *external[GD_T_COUNT]; /* caller-owned device buffers per export slot, or NULL */
+} gd_config;
+
+typedef struct gd_sim gd_sim;
+
+/* Library identity / capability probes (no device access). */
+const char *gd_version(void);
+const char *gd_last_error(void);
+void gd_default_params(gd_params *out);                   /* src/init.hpp:111-127 defaults */
+
+/* Shape/dtype of export slot `id` for (num_worlds, max_agents); data = NULL.  Lets the caller
+ * allocate storage before gd_create.  Replaces the dims lists of src/mgr.cpp:656-902. */
+int gd_tensor_shape(int32_t id, int32_t num_worlds, int32_t max_agents, gd_tensor_desc *out);
+
+/* Manager::Manager (src/mgr.cpp:565; bindings.cpp:93-108): parse `scenes`, build every world,
+ * upload, and run the Reset task graph once so that all tensors hold t = 0 state. */
+int gd_create(const gd_config *cfg, const gd_params *params, const char *const *scenes, gd_sim **out);
+/* Manager::~Manager */
+void gd_destroy(gd_sim *sim);
+
+/* Manager::step (src/mgr.cpp:569-580): movement -> collision -> reward -> --t -> done -> obs.
+ * Launches on cfg.stream and returns without synchronising (stream order = data order). */
+int gd_step(gd_sim *sim);
+/* Manager::reset (src/mgr.cpp:582-588): flag the listed worlds, run the Reset graph for ALL worlds. */
+int gd_reset(gd_sim *sim, const int32_t *world_indices, int32_t n);
+/* Manager::setMaps (src/mgr.cpp:590-654): n must equal num_worlds. */
+int gd_set_maps(gd_sim *sim, const char *const *scenes, int32_t n);
+/* Manager::deleteAgents (src/mgr.cpp:665-715): CSR lists; ids[offsets[i]..offsets[i+1]) for worlds[i]. */
+int gd_delete_agents(gd_sim *sim, const int32_t *worlds, const int32_t *offsets, const int32_t *ids,
+                     int32_t n_worlds);
+/* Manager::*Tensor() (src/mgr.cpp:656-902). */
+int gd_tensor(gd_sim *sim, int32_t id, gd_tensor_desc *out);
+/* Block until everything launched so far has finished (the reference's step() is synchronous). */
+int gd_sync(gd_sim *sim);
+/* Change the launch stream (e.g. torch's current stream). */
+int gd_set_stream(gd_sim *sim, void *stream);
+
+/* Timing hooks for the bench: HIP events around the named kernel on the engine's stream.
+ * kernel: 0 = state step, 1 = road observation, 2 = partner observation. */
+int gd_kernel_timing_enable(gd_sim *sim, int32_t enable);
+int gd_kernel_timing_read(gd_sim *sim, int32_t kernel, double *total_ms, int64_t *launches);
+
+/* Internal agent state for teacher-forced parity tests: 11 floats per agent slot
+ * {pos xyz, quat wxyz, vel xyz, collided}.  Device-to-host / host-to-device copies. */
+int gd_debug_get_state(gd_sim *sim, float *host_out);
+int gd_debug_set_state(gd_sim *sim, const float *host_in);
+
+/* Host-only scene pipeline (no device): parse + build world `scene` exactly as gd_create would
+ * and return the init-time rows, for CPU tests of the host logic.
+ * Replaces MapReader::parseAndWriteOut + createPersistentEntities (src/MapReader.cpp:55-61,
+ * src/level_gen.cpp:396-465).  Caller frees with gd_host_world_free. */
+typedef struct gd_host_world {
+    int32_t num_agents, num_roads, num_collidable_roads, max_agents;
+    float mean[3];
+    int32_t map_name[32], scenario_id[32];
+    float *map_obs;          /* [10000][9] */
+    float *trajectory;       /* [A][1456] */
+    int32_t *controlled, *response_type, *agent_id, *entity_type, *metadata /* [A][4] */;
+    float *vehicle_size;     /* [A][3] */
+    float *goal;             /* [A][2] */
+} gd_host_world;
+int gd_host_world_build(const char *scene, const gd_params *params, int32_t max_agents,
+                        const int32_t *deleted_ids, int32_t n_deleted, gd_host_world *out);
+void gd_host_world_free(gd_host_world *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUDRIVE_AMD_H */

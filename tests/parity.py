@@ -1,0 +1,151 @@
+"""Helpers for the GPU parity suite: build the HIP sim and the oracle on the same scenes and
+parameters, and compare every exported tensor.
+
+Tolerances (BASELINE.json north_star): collision/done/info flags and every int tensor bit-exact;
+fp32 observations within 1e-5 of the oracle GIVEN IDENTICAL INPUT STATE.  Device libm (OCML) and
+host libm (glibc) differ by 1-2 ulp in sinf/cosf/atan2f, and one ulp of a 200 m coordinate is
+1.5e-5, so after a free-running dynamics step positions are compared with rtol 1e-6 + atol 1e-5;
+observations are compared after the oracle's state has been injected into the HIP engine
+(teacher forcing)."""
+import numpy as np
+
+from tests.ref_cases import as_np, write_actions
+
+OBS_ATOL = 1e-5
+STATE_RTOL = 1e-6
+STATE_ATOL = 1e-5
+
+PARAM_KEYS = ("polylineReductionThreshold", "observationRadius", "rewardType", "distanceToGoalThreshold",
+              "distanceToExpertThreshold", "collisionBehaviour", "maxNumControlledAgents", "IgnoreNonVehicles",
+              "roadObservationAlgorithm", "initOnlyValidAgentsAtFirstStep", "isStaticAgentControlled",
+              "enableLidar", "disableClassicalObs", "dynamicsModel", "readFromTracksToPredict")
+
+
+def make_gpu_sim(scenes, max_agents=64, **kw):
+    import madrona_gpudrive as mg
+    p = mg.Parameters()
+    for k, v in kw.items():
+        assert k in PARAM_KEYS, k
+        if k in ("rewardType", "distanceToGoalThreshold", "distanceToExpertThreshold"):
+            setattr(p.rewardParams, k, v)
+        else:
+            setattr(p, k, v)
+    return mg.SimManager(exec_mode=mg.madrona.ExecMode.CUDA, gpu_id=0, scenes=list(scenes), params=p,
+                         max_agents=max_agents)
+
+
+def make_oracle_sim(O, scenes, max_agents=64, **kw):
+    return O.OracleSim(list(scenes), O.default_params(**kw), max_agents=max_agents)
+
+
+INT_TENSORS = ["done_tensor", "info_tensor", "steps_remaining_tensor", "shape_tensor", "controlled_state_tensor",
+               "response_type_tensor", "metadata_tensor", "deleted_agents_tensor", "map_name_tensor",
+               "scenario_id_tensor"]
+STATIC_FLOAT_TENSORS = ["expert_trajectory_tensor", "world_means_tensor", "map_observation_tensor"]
+OBS_TENSORS = ["reward_tensor", "self_observation_tensor", "absolute_self_observation_tensor",
+               "partner_observations_tensor", "agent_roadmap_tensor"]
+
+
+def _live_mask(orc):
+    shape = orc.shape_tensor()
+    W, A = orc.W, orc.A
+    return np.arange(A)[None, :] < shape[:, 0:1]
+
+
+def compare_ints(gpu, orc, names=INT_TENSORS):
+    for name in names:
+        g = as_np(getattr(gpu, name)())
+        o = np.asarray(getattr(orc, name)())
+        assert g.shape == o.shape, (name, g.shape, o.shape)
+        if not np.array_equal(g, o):
+            bad = np.argwhere(g != o)
+            raise AssertionError("%s differs at %d places, first %s: gpu %s oracle %s" %
+                                 (name, len(bad), bad[0], g[tuple(bad[0])], o[tuple(bad[0])]))
+
+
+def compare_static(gpu, orc):
+    for name in STATIC_FLOAT_TENSORS:
+        g = as_np(getattr(gpu, name)())
+        o = np.asarray(getattr(orc, name)())
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), name + " is not bit-identical"
+
+
+def compare_obs(gpu, orc, atol=OBS_ATOL, rtol=0.0, names=OBS_TENSORS, live_only=("absolute_self_observation_tensor",)):
+    live = _live_mask(orc)
+    for name in names:
+        g = as_np(getattr(gpu, name)())
+        o = np.asarray(getattr(orc, name)())
+        assert g.shape == o.shape, (name, g.shape, o.shape)
+        if name in live_only:  # rows of padding agents are never written by the reference
+            g = g[live]
+            o = o[live]
+        if name == "absolute_self_observation_tensor":
+            ok = np.isclose(g, o, atol=atol, rtol=max(rtol, STATE_RTOL))
+        else:
+            ok = np.isclose(g, o, atol=atol, rtol=rtol)
+        if not ok.all():
+            bad = np.argwhere(~ok)
+            raise AssertionError("%s: %d elements beyond atol %g; first at %s gpu %r oracle %r" %
+                                 (name, len(bad), atol, bad[0], g[tuple(bad[0])], o[tuple(bad[0])]))
+
+
+def compare_state(gpu, orc):
+    gs = gpu.debug_get_state()
+    os_ = orc.get_state()
+    live = _live_mask(orc)
+    assert np.array_equal(gs[..., 10][live], os_[..., 10][live]), "collided flags differ"
+    g = gs[live][:, :10]
+    o = os_[live][:, :10]
+    ok = np.isclose(g, o, rtol=STATE_RTOL, atol=STATE_ATOL)
+    if not ok.all():
+        bad = np.argwhere(~ok)
+        raise AssertionError("agent state differs: %d elements, first %s gpu %r oracle %r" %
+                             (len(bad), bad[0], g[tuple(bad[0])], o[tuple(bad[0])]))
+
+
+def random_actions(rng, W, A, model):
+    """Seeded U(-3,2) x U(-0.7,0.7) (reference src/headless.cpp:69-70); deltas / states for the
+    other models."""
+    act = np.zeros((W, A, 10), np.float32)
+    if model in (0, 1):
+        act[..., 0] = rng.uniform(-3.0, 2.0, (W, A))
+        act[..., 1] = rng.uniform(-0.7, 0.7, (W, A))
+    elif model == 2:
+        act[..., 0] = rng.uniform(-0.5, 1.5, (W, A))
+        act[..., 1] = rng.uniform(-0.2, 0.2, (W, A))
+        act[..., 2] = rng.uniform(-0.1, 0.1, (W, A))
+    else:
+        act[..., 0] = rng.uniform(-60, 60, (W, A))
+        act[..., 1] = rng.uniform(-60, 60, (W, A))
+        act[..., 2] = 1.0
+        act[..., 3] = rng.uniform(-3.1, 3.1, (W, A))
+        act[..., 4] = rng.uniform(-8, 8, (W, A))
+        act[..., 5] = rng.uniform(-8, 8, (W, A))
+    return act
+
+
+def lockstep(gpu, orc, steps, model, seed=0, teacher_force=True, check_every=1):
+    """Step both simulators on the same seeded actions.  After every step: int tensors exact, agent
+    state close; then the oracle's state is injected into the HIP engine, both recompute through
+    the Reset graph (no movement, no decrement) and all observations must agree to 1e-5."""
+    rng = np.random.default_rng(seed)
+    W, A = orc.W, orc.A
+    for k in range(steps):
+        act = random_actions(rng, W, A, model)
+        write_actions(gpu, act)
+        np.copyto(orc.action_tensor(), act)
+        gpu.step()
+        orc.step()
+        if k % check_every:
+            continue
+        try:
+            compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+            compare_state(gpu, orc)
+            if teacher_force:
+                gpu.debug_set_state(orc.get_state())
+                gpu.reset([])
+                orc.reset([])
+                compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+                compare_obs(gpu, orc)
+        except AssertionError as e:
+            raise AssertionError("step %d: %s" % (k + 1, e))

@@ -1,0 +1,243 @@
+"""GPU suite (-m gpu): the HIP path, called through the drop-in `madrona_gpudrive` module and the
+C ABI, against the oracle on the same seeded inputs, plus the reference's own known-answer cases
+and size-independent properties at the BASELINE.json sizes.  Nothing here reads /root/reference."""
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import parity as P
+from tests import ref_cases as RC
+from tests.conftest import SCENE_4, SCENE_407, TEST_JSON
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def make_gpu():
+    def _mk(scenes, max_agents=128, **kw):
+        return P.make_gpu_sim(scenes, max_agents=max_agents, **kw)
+    return _mk
+
+
+def test_native_library_is_loaded():
+    import madrona_gpudrive  # noqa: F401
+    from gpudrive_lab_amd import _capi
+    _capi.lib()
+    assert "libgpudrive_amd.so" in open("/proc/self/maps").read()
+
+
+def test_cpu_exec_mode_is_refused():
+    import madrona_gpudrive as mg
+    with pytest.raises(RuntimeError):
+        mg.SimManager(mg.madrona.ExecMode.CPU, 0, [TEST_JSON], mg.Parameters())
+
+
+def test_missing_scene_raises_not_aborts():
+    import madrona_gpudrive as mg
+    with pytest.raises(FileNotFoundError):
+        mg.SimManager(mg.madrona.ExecMode.CUDA, 0, ["/nonexistent.json"], mg.Parameters(), max_agents=64)
+
+
+# ---- the reference's own tests, run on the HIP path ----
+def test_ref_bicycle_model(make_gpu):
+    RC.check_bicycle_model(make_gpu, TEST_JSON)
+
+
+def test_ref_map_observation(make_gpu):
+    RC.check_map_observation(make_gpu, TEST_JSON)
+
+
+def test_ref_delta_model(make_gpu):
+    RC.check_delta_model(make_gpu, TEST_JSON)
+
+
+def test_ref_waymax_model(make_gpu):
+    RC.check_waymax_model(make_gpu, TEST_JSON)
+
+
+def test_ref_expert_replay(make_gpu):
+    RC.check_expert_replay(make_gpu, TEST_JSON)
+
+
+# ---- lockstep parity against the oracle ----
+ALL_OBJECTS = dict(isStaticAgentControlled=1, initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
+
+LOCKSTEP = [
+    # BASELINE configs[0]: 1 scene, 1 world, delta dynamics (tests/test_delta_model.py:7-27)
+    ("cfg0_delta", [TEST_JSON], 128, 40, dict(polylineReductionThreshold=0.5, observationRadius=10.0, collisionBehaviour=0,
+                                               rewardType=0, distanceToGoalThreshold=1.0, maxNumControlledAgents=2,
+                                               IgnoreNonVehicles=1, dynamicsModel=2)),
+    # configs[1]: classic, k-NN roads, radius 50, threshold 0.1, collisions ignored
+    ("cfg1_classic_knn", [TEST_JSON, SCENE_407, SCENE_4, SCENE_4], 64, 95,
+     dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+          distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)),
+    # configs[2]: collisions on (AgentStop), goal-reach reward
+    ("cfg2_agent_stop", [SCENE_4, SCENE_407, TEST_JSON], 64, 95,
+     dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
+          distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)),
+    ("agent_removed_bicycle", [SCENE_4, SCENE_407], 64, 60,
+     dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=1, rewardType=0,
+          distanceToGoalThreshold=2.0, dynamicsModel=1, **ALL_OBJECTS)),
+    ("linear_roads_fork128", [SCENE_4, TEST_JSON], 128, 30,
+     dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+          distanceToGoalThreshold=2.0, roadObservationAlgorithm=1, dynamicsModel=0, **ALL_OBJECTS)),
+    ("state_model", [SCENE_407], 64, 10,
+     dict(polylineReductionThreshold=0.5, observationRadius=50.0, collisionBehaviour=2, rewardType=0,
+          distanceToGoalThreshold=2.0, dynamicsModel=3, **ALL_OBJECTS)),
+    # unreduced polylines: R = 9899 > K, long heap histories
+    ("knn_unreduced", [TEST_JSON], 64, 4,
+     dict(polylineReductionThreshold=0.0, observationRadius=100.0, collisionBehaviour=2, rewardType=1,
+          distanceToGoalThreshold=2.0, dynamicsModel=0, initOnlyValidAgentsAtFirstStep=0)),
+    # expert replay only (no controlled agents), default init rules
+    ("experts_only", [SCENE_4], 64, 95,
+     dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
+          distanceToGoalThreshold=2.0, maxNumControlledAgents=0, IgnoreNonVehicles=1)),
+]
+
+
+@pytest.mark.parametrize("name,scenes,A,steps,kw", LOCKSTEP, ids=[c[0] for c in LOCKSTEP])
+def test_lockstep_parity(oracle_mod, name, scenes, A, steps, kw):
+    gpu = P.make_gpu_sim(scenes, max_agents=A, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=A, **kw)
+    # t = 0: everything the constructor leaves behind
+    P.compare_ints(gpu, orc)
+    P.compare_static(gpu, orc)
+    P.compare_state(gpu, orc)
+    P.compare_obs(gpu, orc)
+    P.lockstep(gpu, orc, steps, kw.get("dynamicsModel", 0), seed=zlib.crc32(name.encode()) % 1000)
+    gpu.close()
+
+
+def test_free_running_flags_stay_exact(oracle_mod):
+    """No teacher forcing: 91 steps + reset + 30 steps; int tensors must stay bit-exact."""
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
+    scenes = [SCENE_4, SCENE_407, TEST_JSON]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    P.lockstep(gpu, orc, 91, 0, seed=7, teacher_force=False)
+    gpu.reset([0, 2])
+    orc.reset([0, 2])
+    P.compare_ints(gpu, orc)
+    P.compare_state(gpu, orc)
+    P.lockstep(gpu, orc, 30, 0, seed=8, teacher_force=False)
+    gpu.close()
+
+
+def test_partial_reset_set_maps_delete_agents(oracle_mod):
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
+    scenes = [SCENE_4, SCENE_407, TEST_JSON]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    P.lockstep(gpu, orc, 5, 0, seed=1)
+    # reset(int), reset(ndarray) (gpudrive sb3_wrapper.py:163, env_puffer.py:376)
+    gpu.reset(1)
+    orc.reset(1)
+    P.compare_ints(gpu, orc)
+    P.compare_obs(gpu, orc)
+    gpu.reset(np.array([0, 2]))
+    orc.reset([0, 2])
+    P.compare_ints(gpu, orc)
+    P.compare_obs(gpu, orc)
+    # set_maps: len must match; worlds rebuilt; views stay valid
+    view = gpu.shape_tensor().to_torch()
+    with pytest.raises(ValueError):
+        gpu.set_maps([TEST_JSON])
+    new = [TEST_JSON, SCENE_4, SCENE_407]
+    gpu.set_maps(new)
+    orc.set_maps(new)
+    assert view.data_ptr() == gpu.shape_tensor().to_torch().data_ptr()
+    P.compare_ints(gpu, orc)
+    P.compare_static(gpu, orc)
+    P.compare_obs(gpu, orc)
+    P.lockstep(gpu, orc, 3, 0, seed=2)
+    # deleteAgents
+    ids = np.asarray(orc.agent_id_tensor())
+    victims = {1: [int(ids[1, 0]), int(ids[1, 5])], 2: [int(ids[2, 1])]}
+    gpu.deleteAgents(victims)
+    orc.deleteAgents(victims)
+    P.compare_ints(gpu, orc)
+    P.compare_static(gpu, orc)
+    P.compare_obs(gpu, orc)
+    P.lockstep(gpu, orc, 3, 0, seed=3)
+    with pytest.raises(FileNotFoundError):
+        gpu.set_maps(["/nonexistent.json"] * 3)
+    P.lockstep(gpu, orc, 2, 0, seed=4)  # engine still usable after a failed set_maps
+    gpu.close()
+
+
+def test_in_place_action_writes_and_aliasing():
+    """Python mutates the exported action tensor in place (env_torch.py:645-664)."""
+    import torch
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
+    gpu = P.make_gpu_sim([SCENE_407], max_agents=64, **kw)
+    a1 = gpu.action_tensor().to_torch()
+    a2 = gpu.action_tensor().to_torch()
+    assert a1.data_ptr() == a2.data_ptr() and a1.is_cuda
+    before = gpu.absolute_self_observation_tensor().to_torch().clone()
+    a1[:, :, :3].copy_(torch.tensor([2.0, 0.0, 0.0], device=a1.device).expand(1, 64, 3))
+    gpu.step()
+    after = gpu.absolute_self_observation_tensor().to_torch()
+    ctrl = gpu.controlled_state_tensor().to_torch()[0, :, 0] == 1
+    assert ctrl.any()
+    assert (before[0, ctrl, :2] != after[0, ctrl, :2]).any()
+    gpu.close()
+
+
+# ---- BASELINE.json full sizes: size-independent properties ----
+def _tiled(n):
+    base = [TEST_JSON, SCENE_407, SCENE_4]
+    return [base[i % 3] for i in range(n)]
+
+
+@pytest.mark.parametrize("W,collision", [(1024, 2), (4096, 0)])
+def test_full_size_properties(W, collision):
+    """configs[1] (1024 worlds) and configs[2] (4096 worlds, collisions on): worlds tiled from the
+    same scene and fed the same actions must stay identical replicas (checksum of checksums);
+    k-NN rows must be within the radius, unique, and no unselected road may be closer than a
+    selected one."""
+    import torch
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=collision, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
+    gpu = P.make_gpu_sim(_tiled(W), max_agents=64, **kw)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    act3 = torch.zeros(3, 64, 10)
+    for step in range(12):
+        act3[..., 0] = torch.rand(3, 64, generator=g) * 5 - 3
+        act3[..., 1] = torch.rand(3, 64, generator=g) * 1.4 - 0.7
+        a = gpu.action_tensor().to_torch()
+        a.copy_(act3.repeat((W + 2) // 3, 1, 1)[:W].to(a.device))
+        gpu.step()
+    names = ["done_tensor", "info_tensor", "reward_tensor", "self_observation_tensor",
+             "absolute_self_observation_tensor", "partner_observations_tensor", "agent_roadmap_tensor"]
+    for name in names:
+        t = getattr(gpu, name)().to_torch()
+        flat = t.reshape(W, -1)
+        for r in range(3):
+            grp = flat[r::3]
+            assert torch.equal(grp, grp[0:1].expand_as(grp)), "%s: replicas of scene %d diverged" % (name, r)
+    # k-NN selection properties on world 0..2
+    am = gpu.agent_roadmap_tensor().to_torch()[:3].cpu().numpy()
+    shape = gpu.shape_tensor().to_torch()[:3].cpu().numpy()
+    mo = gpu.map_observation_tensor().to_torch()[:3].cpu().numpy()
+    ab = gpu.absolute_self_observation_tensor().to_torch()[:3].cpu().numpy()
+    for w in range(3):
+        n, R = shape[w]
+        for a in range(n):
+            rows = am[w, a]
+            valid = rows[:, 6] != 0
+            d = np.hypot(rows[valid, 0], rows[valid, 1])
+            assert (d <= 50.0 + 1e-4).all()
+            # padding rows of the k-NN path are all-zero (src/knn.hpp:19-28)
+            assert (rows[~valid] == 0).all()
+            # every road within the radius that is closer than the farthest selected one is selected
+            dist_all = np.hypot(mo[w, :R, 0] - ab[w, a, 0], mo[w, :R, 1] - ab[w, a, 1])
+            within = np.sort(dist_all[dist_all <= 50.0 - 1e-3])
+            if len(within) <= 200:
+                assert valid.sum() >= len(within)
+            else:
+                assert valid.sum() == 200 and d.max() <= within[199] + 1e-3
+    gpu.close()
