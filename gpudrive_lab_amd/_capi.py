@@ -90,6 +90,10 @@ def lib():
         raise ImportError(
             "gpudrive_lab_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the step path." % _SO)
+    # torch-ROCm bundles its own libamdhip64.so.7; load it first so that this library binds to the
+    # SAME HIP runtime instance (two runtimes in one process cannot both own the device, and the
+    # engine is handed torch-allocated device pointers).
+    import torch  # noqa: F401
     L = C.CDLL(_SO)
     L.gd_version.restype = C.c_char_p
     L.gd_last_error.restype = C.c_char_p

@@ -27,13 +27,34 @@ enum : int { ET_None = 0, ET_RoadEdge, ET_RoadLine, ET_RoadLane, ET_CrossWalk, E
              ET_Vehicle, ET_Pedestrian, ET_Cyclist, ET_Padding };
 enum : int { RESP_Dynamic = 0, RESP_Kinematic = 1, RESP_Static = 2 };
 
+// Transcendentals of per-agent state (pose, dynamics, agent boxes).  The reference evaluates them
+// with the host libm in float.  On the device they are evaluated in double and rounded once
+// (fp64 is cheap on CDNA4 and there are only O(agents) such calls per step): the result is the
+// correctly rounded float, which is what glibc's sinf/cosf return in all but rare cases, whereas
+// OCML's float versions differ from glibc by 1-2 ulp far more often.  One ulp of a quaternion
+// component moves an egocentric coordinate at 50 m by ~1e-5, the whole parity budget.
+// Observation-row headings keep the float atan2f (their error, <1e-6 rad, is harmless).
+#if defined(__HIP_DEVICE_COMPILE__)
+GD_HD float p_sin(float x) { return (float)sin((double)x); }
+GD_HD float p_cos(float x) { return (float)cos((double)x); }
+GD_HD float p_tan(float x) { return (float)tan((double)x); }
+GD_HD float p_atan(float x) { return (float)atan((double)x); }
+GD_HD float p_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+#else
+GD_HD float p_sin(float x) { return sinf(x); }
+GD_HD float p_cos(float x) { return cosf(x); }
+GD_HD float p_tan(float x) { return tanf(x); }
+GD_HD float p_atan(float x) { return atanf(x); }
+GD_HD float p_atan2(float y, float x) { return atan2f(y, x); }
+#endif
+
 struct Quat { float w, x, y, z; };
 struct V3 { float x, y, z; };
 struct V2 { float x, y; };
 
 // Quat::angleAxis(a, up): {cos(a/2), up * sin(a/2)} with up = (0,0,1)
 GD_HD Quat quat_yaw(float a) {
-    float c = cosf(a / 2.f), s = sinf(a / 2.f);
+    float c = p_cos(a / 2.f), s = p_sin(a / 2.f);
     return Quat{c, 0.f * s, 0.f * s, 1.f * s};
 }
 // Every rotation in the simulator is a yaw rotation; it is stored as (w, z) and the x/y
@@ -67,6 +88,10 @@ GD_HD float normalize_angle(float angle) {
 }
 GD_HD float angle_add(float a, float b) { return normalize_angle(a + b); }
 GD_HD float quat_to_yaw(Quat q) {
+    return p_atan2(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
+}
+// observation-row variant (hundreds per agent per step): plain float atan2f
+GD_HD float quat_to_yaw_row(Quat q) {
     return atan2f(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
 }
 
@@ -84,8 +109,8 @@ struct Obb {
 };
 GD_HD Obb obb_from(float px, float py, Quat rot, float d0, float d1) {
     float theta = quat_to_yaw(rot);
-    float Xx = cosf(theta), Xy = sinf(theta);
-    float Yx = -sinf(theta), Yy = cosf(theta);
+    float Xx = p_cos(theta), Xy = p_sin(theta);
+    float Yx = -p_sin(theta), Yy = p_cos(theta);
     Xx *= d0; Xy *= d0;
     Yx *= d1; Yy *= d1;
     Obb o;

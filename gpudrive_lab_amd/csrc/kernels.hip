@@ -36,19 +36,19 @@ __device__ __forceinline__ void forward_classic(const float *act, float length, 
     const float speed = len_3(b.vx, b.vy, b.vz);
     const float yaw = quat_to_yaw(quat_from_wz(b.qw, b.qz));
     const float v = fmaxf(fminf(speed + 0.5f * act[0] * dt, maxSpeed), -maxSpeed);
-    const float tanDelta = tanf(act[1]);
-    const float beta = atanf(0.5f * tanDelta);
-    const float dx = v * cosf(yaw + beta), dy = v * sinf(yaw + beta);
-    const float w = v * cosf(beta) * tanDelta / length;
+    const float tanDelta = p_tan(act[1]);
+    const float beta = p_atan(0.5f * tanDelta);
+    const float dx = v * p_cos(yaw + beta), dy = v * p_sin(yaw + beta);
+    const float w = v * p_cos(beta) * tanDelta / length;
     const float new_yaw = angle_add(yaw, w * dt);
     const float new_speed = fmaxf(fminf(speed + act[0] * dt, maxSpeed), -maxSpeed);
     b.px += dx * dt;
     b.py += dy * dt;
     b.pz = 1.f;
-    b.qw = cosf(new_yaw / 2.f);
-    b.qz = sinf(new_yaw / 2.f);
-    b.vx = new_speed * cosf(new_yaw);
-    b.vy = new_speed * sinf(new_yaw);
+    b.qw = p_cos(new_yaw / 2.f);
+    b.qz = p_sin(new_yaw / 2.f);
+    b.vx = new_speed * p_cos(new_yaw);
+    b.vy = new_speed * p_sin(new_yaw);
     b.vz = 0.f;
 }
 
@@ -58,22 +58,22 @@ __device__ __forceinline__ void forward_bicycle(float *act, Body &b) {  // :52-8
     const float dt = 0.1f;
     const float yaw = quat_to_yaw(quat_from_wz(b.qw, b.qz));
     const float speed = len_3(b.vx, b.vy, b.vz);
-    b.px = (float)((double)(b.px + b.vx * dt) + 0.5 * act[0] * cosf(yaw) * dt * dt);
-    b.py = (float)((double)(b.py + b.vy * dt) + 0.5 * act[0] * sinf(yaw) * dt * dt);
+    b.px = (float)((double)(b.px + b.vx * dt) + 0.5 * act[0] * p_cos(yaw) * dt * dt);
+    b.py = (float)((double)(b.py + b.vy * dt) + 0.5 * act[0] * p_sin(yaw) * dt * dt);
     const float delta_yaw = (float)(act[1] * ((double)(speed * dt) + 0.5 * act[0] * dt * dt));
     const float new_yaw = angle_add(yaw, delta_yaw);
     const float new_speed = speed + act[0] * dt;
-    b.vx = new_speed * cosf(new_yaw);
-    b.vy = new_speed * sinf(new_yaw);
+    b.vx = new_speed * p_cos(new_yaw);
+    b.vy = new_speed * p_sin(new_yaw);
     b.vz = 0.f;
-    b.qw = cosf(new_yaw / 2.f);
-    b.qz = sinf(new_yaw / 2.f);
+    b.qw = p_cos(new_yaw / 2.f);
+    b.qz = p_sin(new_yaw / 2.f);
 }
 
 __device__ __forceinline__ void forward_delta(const float *act, Body &b) {  // :83-115
     const float dt = 0.1f;
     const float yaw = quat_to_yaw(quat_from_wz(b.qw, b.qz));
-    const float c = cosf(yaw), s = sinf(yaw);
+    const float c = p_cos(yaw), s = p_sin(yaw);
     const float dx = act[0] * c - act[1] * s;
     const float dy = act[0] * s + act[1] * c;
     b.px = b.px + dx;
@@ -82,15 +82,15 @@ __device__ __forceinline__ void forward_delta(const float *act, Body &b) {  // :
     b.vy = dy / dt;
     b.vz = 0.f;
     const float new_yaw = angle_add(yaw, act[2]);
-    b.qw = cosf(new_yaw / 2.f);
-    b.qz = sinf(new_yaw / 2.f);
+    b.qw = p_cos(new_yaw / 2.f);
+    b.qz = p_sin(new_yaw / 2.f);
 }
 
 __device__ __forceinline__ void forward_state(const float *act, Body &b) {  // :186-194
     b.px = act[0]; b.py = act[1]; b.pz = act[2];
     b.vx = act[4]; b.vy = act[5]; b.vz = act[6];
-    b.qw = cosf(act[3] / 2.f);
-    b.qz = sinf(act[3] / 2.f);
+    b.qw = p_cos(act[3] / 2.f);
+    b.qz = p_sin(act[3] / 2.f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(A_T) void k_reset_worlds(DevSim d) {
         d.py[i] = t[1];
         d.pz[i] = 1.f;
         const float heading = t[4 * 91];
-        d.qw[i] = cosf(heading / 2.f);
-        d.qz[i] = sinf(heading / 2.f);
+        d.qw[i] = p_cos(heading / 2.f);
+        d.qz[i] = p_sin(heading / 2.f);
         const bool is_static = d.resp[i] == RESP_Static;
         d.vx[i] = is_static ? 0.f : t[2 * 91 + 0];
         d.vy[i] = is_static ? 0.f : t[2 * 91 + 1];
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(A_T) void k_world_step(DevSim d) {
                 b.px = t[2 * k]; b.py = t[2 * k + 1]; b.pz = 1.f;
                 b.vx = t[2 * 91 + 2 * k]; b.vy = t[2 * 91 + 2 * k + 1]; b.vz = 0.f;
                 const float heading = t[4 * 91 + k];
-                b.qw = cosf(heading / 2.f);
-                b.qz = sinf(heading / 2.f);
+                b.qw = p_cos(heading / 2.f);
+                b.qz = p_sin(heading / 2.f);
             }
         }
     }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(A_T) void k_world_step(DevSim d) {
             if (len_2(r.x, r.y) > d.p.observationRadius) {  // zero(): id -1
                 o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -1.f;
             } else {
-                const float heading = quat_to_yaw(quat_mul(ego_inv, quat_from_wz(s_qw[j], s_qz[j])));
+                const float heading = quat_to_yaw_row(quat_mul(ego_inv, quat_from_wz(s_qw[j], s_qz[j])));
                 o[0] = s_speed[j];
                 o[1] = r.x; o[2] = r.y;
                 o[3] = heading;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(A_T) void k_map_obs(DevSim d) {
         const V2 rel = ego_relative(s_ex[ego], s_ey[ego], einv, xy.x, xy.y);
         o[0] = rel.x; o[1] = rel.y;
         o[2] = a0.z; o[3] = a0.w; o[4] = a1.x;
-        o[5] = quat_to_yaw(quat_mul(einv, quat_from_wz(a0.x, a0.y)));
+        o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(a0.x, a0.y)));
         o[6] = a1.y; o[7] = a1.z; o[8] = a1.w;
     }
 }

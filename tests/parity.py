@@ -12,6 +12,10 @@ import numpy as np
 from tests.ref_cases import as_np, write_actions
 
 OBS_ATOL = 1e-5
+# Observations computed from independently evolved state (before injection): one ulp of a
+# quaternion component (cosf/sinf of the half heading, device vs glibc) moves an egocentric
+# coordinate at 50 m by ~1.2e-5, so un-injected comparisons use a looser bound.
+FREE_OBS_ATOL = 5e-5
 STATE_RTOL = 1e-6
 STATE_ATOL = 1e-5
 
@@ -124,6 +128,26 @@ def random_actions(rng, W, A, model):
     return act
 
 
+def inject_and_compare(gpu, orc):
+    """Copy the oracle's agent state into the HIP engine, recompute both through the Reset graph
+    (no movement, no decrement) and require every observation within 1e-5, ints exact."""
+    gpu.debug_set_state(orc.get_state())
+    gpu.reset([])
+    orc.reset([])
+    compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+    compare_obs(gpu, orc)
+
+
+def compare_fresh(gpu, orc):
+    """After construction / reset / set_maps: ints and init-time rows exact, state close,
+    observations within the un-injected bound, then the strict injected comparison."""
+    compare_ints(gpu, orc)
+    compare_static(gpu, orc)
+    compare_state(gpu, orc)
+    compare_obs(gpu, orc, atol=FREE_OBS_ATOL)
+    inject_and_compare(gpu, orc)
+
+
 def lockstep(gpu, orc, steps, model, seed=0, teacher_force=True, check_every=1):
     """Step both simulators on the same seeded actions.  After every step: int tensors exact, agent
     state close; then the oracle's state is injected into the HIP engine, both recompute through
@@ -142,10 +166,6 @@ def lockstep(gpu, orc, steps, model, seed=0, teacher_force=True, check_every=1):
             compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
             compare_state(gpu, orc)
             if teacher_force:
-                gpu.debug_set_state(orc.get_state())
-                gpu.reset([])
-                orc.reset([])
-                compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
-                compare_obs(gpu, orc)
+                inject_and_compare(gpu, orc)
         except AssertionError as e:
             raise AssertionError("step %d: %s" % (k + 1, e))

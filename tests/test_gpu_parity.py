@@ -101,10 +101,7 @@ def test_lockstep_parity(oracle_mod, name, scenes, A, steps, kw):
     gpu = P.make_gpu_sim(scenes, max_agents=A, **kw)
     orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=A, **kw)
     # t = 0: everything the constructor leaves behind
-    P.compare_ints(gpu, orc)
-    P.compare_static(gpu, orc)
-    P.compare_state(gpu, orc)
-    P.compare_obs(gpu, orc)
+    P.compare_fresh(gpu, orc)
     P.lockstep(gpu, orc, steps, kw.get("dynamicsModel", 0), seed=zlib.crc32(name.encode()) % 1000)
     gpu.close()
 
@@ -135,12 +132,10 @@ def test_partial_reset_set_maps_delete_agents(oracle_mod):
     # reset(int), reset(ndarray) (gpudrive sb3_wrapper.py:163, env_puffer.py:376)
     gpu.reset(1)
     orc.reset(1)
-    P.compare_ints(gpu, orc)
-    P.compare_obs(gpu, orc)
+    P.compare_fresh(gpu, orc)
     gpu.reset(np.array([0, 2]))
     orc.reset([0, 2])
-    P.compare_ints(gpu, orc)
-    P.compare_obs(gpu, orc)
+    P.compare_fresh(gpu, orc)
     # set_maps: len must match; worlds rebuilt; views stay valid
     view = gpu.shape_tensor().to_torch()
     with pytest.raises(ValueError):
@@ -149,18 +144,14 @@ def test_partial_reset_set_maps_delete_agents(oracle_mod):
     gpu.set_maps(new)
     orc.set_maps(new)
     assert view.data_ptr() == gpu.shape_tensor().to_torch().data_ptr()
-    P.compare_ints(gpu, orc)
-    P.compare_static(gpu, orc)
-    P.compare_obs(gpu, orc)
+    P.compare_fresh(gpu, orc)
     P.lockstep(gpu, orc, 3, 0, seed=2)
     # deleteAgents
     ids = np.asarray(orc.agent_id_tensor())
     victims = {1: [int(ids[1, 0]), int(ids[1, 5])], 2: [int(ids[2, 1])]}
     gpu.deleteAgents(victims)
     orc.deleteAgents(victims)
-    P.compare_ints(gpu, orc)
-    P.compare_static(gpu, orc)
-    P.compare_obs(gpu, orc)
+    P.compare_fresh(gpu, orc)
     P.lockstep(gpu, orc, 3, 0, seed=3)
     with pytest.raises(FileNotFoundError):
         gpu.set_maps(["/nonexistent.json"] * 3)
