@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -93,6 +94,10 @@ struct gd_sim {
     // per-world host road data (kept to repack the CSR on set_maps / deleteAgents)
     std::vector<std::vector<float>> w_xy, w_aux;
     std::vector<std::vector<gd::RoadBox>> w_boxes;
+    std::vector<gd::GridHdr> w_grid;
+    std::vector<std::vector<int32_t>> w_cell_off, w_cell_items;
+    size_t cell_cap = 0, item_cap = 0;
+    void *d_cell_off = nullptr, *d_cell_items = nullptr;
     size_t road_cap = 0, box_cap = 0;
     void *d_road_xy = nullptr, *d_road_aux = nullptr, *d_boxes = nullptr;
     // pinned flag staging ring
@@ -115,6 +120,8 @@ struct gd_sim {
         if (d_road_xy) (void)hipFree(d_road_xy);
         if (d_road_aux) (void)hipFree(d_road_aux);
         if (d_boxes) (void)hipFree(d_boxes);
+        if (d_cell_off) (void)hipFree(d_cell_off);
+        if (d_cell_items) (void)hipFree(d_cell_items);
         for (int i = 0; i < kRing; i++) {
             if (h_flags[i]) (void)hipHostFree(h_flags[i]);
             if (flag_ev[i]) (void)hipEventDestroy(flag_ev[i]);
@@ -251,6 +258,9 @@ struct gd_sim {
             w_xy[w] = hw->road_xy;
             w_aux[w] = hw->road_aux;
             w_boxes[w] = hw->boxes;
+            w_grid[w] = gd::GridHdr{hw->grid_ox, hw->grid_oy, 1.f / hw->grid_cell, hw->grid_nx, hw->grid_ny, 0, 0, 0};
+            w_cell_off[w] = hw->cell_off;
+            w_cell_items[w] = hw->cell_items;
             rebuilt[w] = 1;
         }
         // repack the road CSR
@@ -285,6 +295,35 @@ struct gd_sim {
                 HIP_CHECK(hipMemcpy(d_road_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice));
             }
             if (nbox) HIP_CHECK(hipMemcpy(d_boxes, boxes.data(), nbox * sizeof(gd::RoadBox), hipMemcpyHostToDevice));
+        }
+        {
+            size_t ncell = 0, nitem = 0;
+            for (int w = 0; w < W; w++) {
+                w_grid[w].cell_base = static_cast<int>(ncell);
+                w_grid[w].item_base = static_cast<int>(nitem);
+                ncell += w_cell_off[w].size();
+                nitem += w_cell_items[w].size();
+            }
+            if (ncell > cell_cap) {
+                if (d_cell_off) (void)hipFree(d_cell_off);
+                cell_cap = ncell + ncell / 8 + 64;
+                HIP_CHECK(hipMalloc(&d_cell_off, cell_cap * sizeof(int32_t)));
+            }
+            if (nitem > item_cap) {
+                if (d_cell_items) (void)hipFree(d_cell_items);
+                item_cap = nitem + nitem / 8 + 64;
+                HIP_CHECK(hipMalloc(&d_cell_items, item_cap * sizeof(int32_t)));
+            }
+            std::vector<int32_t> co(ncell), ci(nitem);
+            for (int w = 0; w < W; w++) {
+                std::copy(w_cell_off[w].begin(), w_cell_off[w].end(), co.begin() + w_grid[w].cell_base);
+                std::copy(w_cell_items[w].begin(), w_cell_items[w].end(), ci.begin() + w_grid[w].item_base);
+            }
+            if (ncell) HIP_CHECK(hipMemcpy(d_cell_off, co.data(), ncell * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (nitem) HIP_CHECK(hipMemcpy(d_cell_items, ci.data(), nitem * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(const_cast<gd::GridHdr *>(d.grid), w_grid.data(), sizeof(gd::GridHdr) * W, hipMemcpyHostToDevice));
+            d.cell_off = static_cast<const int32_t *>(d_cell_off);
+            d.cell_items = static_cast<const int32_t *>(d_cell_items);
         }
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.road_off), road_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.box_off), box_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
@@ -376,6 +415,9 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         s->w_xy.resize(W);
         s->w_aux.resize(W);
         s->w_boxes.resize(W);
+        s->w_grid.resize(W);
+        s->w_cell_off.resize(W);
+        s->w_cell_items.resize(W);
         for (int id = 0; id < GD_T_COUNT; id++) {
             if (id == GD_T_BEV && !cfg->alloc_bev && !cfg->external[id]) continue;
             const int64_t bytes = spec_bytes(tensor_spec(id, W, A));
@@ -391,6 +433,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.W = W;
         d.A = A;
         d.p = *params;
+        d.debug_flags = std::getenv("GPUDRIVE_DEBUG_FLAGS") ? std::atoi(std::getenv("GPUDRIVE_DEBUG_FLAGS")) : 0;
         d.action = static_cast<float *>(s->exported[GD_T_ACTION]);
         d.reward = static_cast<float *>(s->exported[GD_T_REWARD]);
         d.done = static_cast<int32_t *>(s->exported[GD_T_DONE]);
@@ -426,6 +469,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.rebuilt_flags = s->alloc_internal<int32_t>(W);
         d.road_off = s->alloc_internal<int32_t>(W + 1);
         d.box_off = s->alloc_internal<int32_t>(W + 1);
+        d.grid = s->alloc_internal<gd::GridHdr>(W);
         for (int i = 0; i < gd_sim::kRing; i++) {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->h_flags[i]), sizeof(int32_t) * W, hipHostMallocDefault));
             HIP_CHECK(hipEventCreateWithFlags(&s->flag_ev[i], hipEventDisableTiming));

@@ -10,6 +10,15 @@ namespace gd {
 
 enum { KERNEL_STATE = 0, KERNEL_MAP_OBS = 1, KERNEL_PARTNER = 2, KERNEL_RESET = 3, KERNEL_PADDING = 4 };
 
+// Per-world broadphase grid header (see HostWorld in scene.hpp).
+struct GridHdr {
+    float ox, oy, inv_cell;
+    int nx, ny;
+    int cell_base;  // first entry of this world in cell_off
+    int item_base;  // first entry of this world in cell_items
+    int pad;
+};
+
 // Passed to kernels by value.  HBM layout:
 //   exported tensors : the reference's AoS layouts (API contract, src/mgr.cpp:656-902)
 //   agent state      : world-major SoA, one [W][A] plane per field
@@ -18,6 +27,7 @@ enum { KERNEL_STATE = 0, KERNEL_MAP_OBS = 1, KERNEL_PARTNER = 2, KERNEL_RESET = 
 //   collidable boxes : CSR over worlds; 5 x float4 per box {cx,cy,radius,type | 14-float OBB}
 struct DevSim {
     int W, A;
+    int debug_flags;  // developer ablation switches (GPUDRIVE_DEBUG_FLAGS), 0 in production
     gd_params p;
     // exported
     float *action, *reward, *self_obs, *abs_obs, *partner, *agent_map, *map_obs, *lidar, *bev, *traj, *means;
@@ -36,8 +46,12 @@ struct DevSim {
     const float4 *road_aux;
     const int32_t *box_off;   // [W+1]
     const float4 *boxes;
+    const GridHdr *grid;        // [W]
+    const int32_t *cell_off;    // per world nx*ny+1 entries, local offsets
+    const int32_t *cell_items;  // local box indices
 };
 
 void launch_kernel(const DevSim &d, hipStream_t st, int which, bool move);
+void launch_map_obs(const DevSim &d, hipStream_t st);  // map_obs.hip
 
 }  // namespace gd

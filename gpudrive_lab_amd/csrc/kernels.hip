@@ -318,27 +318,33 @@ __global__ __launch_bounds__(A_T) void k_world_step(DevSim d) {
             else if (otype <= ET_Cyclist) info2 = 1;
         }
         if (!me_static) {
-            const int b0 = d.box_off[w], b1 = d.box_off[w + 1];
-            for (int r = b0; r < b1; r++) {
-                const float4 hdr = d.boxes[(size_t)r * 5];
-                const int rtype = (int)hdr.w;
-                if (collision_pair_filtered(etype, rtype)) continue;
-                const float dx = b.px - hdr.x, dy = b.py - hdr.y;
-                const float rr = (my_rad + hdr.z) * 1.001f + 0.01f;
-                if (dx * dx + dy * dy > rr * rr) continue;
-                Obb ro;
-                float4 *rf = reinterpret_cast<float4 *>(&ro);  // 14 floats + 2 pad
-                const float4 q1 = d.boxes[(size_t)r * 5 + 1], q2 = d.boxes[(size_t)r * 5 + 2],
-                             q3 = d.boxes[(size_t)r * 5 + 3], q4 = d.boxes[(size_t)r * 5 + 4];
-                float tmp[16] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
-                                 q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
-                float *of = reinterpret_cast<float *>(&ro);
+            // road boxes of the broadphase cell under the agent's centre
+            const GridHdr gh = d.grid[w];
+            const float fx = (b.px - gh.ox) * gh.inv_cell, fy = (b.py - gh.oy) * gh.inv_cell;
+            if (gh.nx > 0 && fx >= 0.f && fy >= 0.f && fx < (float)gh.nx && fy < (float)gh.ny) {
+                const int cell = (int)fy * gh.nx + (int)fx;
+                const int c0 = d.cell_off[gh.cell_base + cell], c1 = d.cell_off[gh.cell_base + cell + 1];
+                const int bbase = d.box_off[w];
+                for (int c = c0; c < c1; c++) {
+                    const size_t r = (size_t)(bbase + d.cell_items[gh.item_base + c]);
+                    const float4 hdr = d.boxes[r * 5];
+                    const int rtype = (int)hdr.w;
+                    if (collision_pair_filtered(etype, rtype)) continue;
+                    const float dx = b.px - hdr.x, dy = b.py - hdr.y;
+                    const float rr = (my_rad + hdr.z) * 1.001f + 0.01f;
+                    if (dx * dx + dy * dy > rr * rr) continue;
+                    const float4 q1 = d.boxes[r * 5 + 1], q2 = d.boxes[r * 5 + 2], q3 = d.boxes[r * 5 + 3],
+                                 q4 = d.boxes[r * 5 + 4];
+                    const float tmp[16] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                                           q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
+                    Obb ro;
+                    float *of = reinterpret_cast<float *>(&ro);
 #pragma unroll
-                for (int k = 0; k < 14; k++) of[k] = tmp[k];
-                (void)rf;
-                if (!obb_collided(me, ro)) continue;
-                collided = 1;
-                if (rtype > ET_None && rtype <= ET_StopSign) info0 = 1;
+                    for (int k = 0; k < 14; k++) of[k] = tmp[k];
+                    if (!obb_collided(me, ro)) continue;
+                    collided = 1;
+                    if (rtype > ET_None && rtype <= ET_StopSign) info0 = 1;
+                }
             }
         }
     }
@@ -419,166 +425,6 @@ __global__ __launch_bounds__(A_T) void k_world_step(DevSim d) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// road observations: collectMapObservationsSystem (src/sim.cpp:242-280) with
-// selectKNearestRoadEntities (src/knn.hpp:103-158) on the SGI heap (src/binary_heap.hpp).
-//
-// One lane per agent.  Each lane keeps its own 200-entry heap in LDS, slot-major
-// (keys[slot][lane]) so that a lane always hits its own bank whatever slot it touches.  The
-// road (x, y) stream is staged through an LDS tile shared by all lanes of the world, so road
-// bytes leave HBM once per world.  The heap replay reproduces the reference's row ORDER, which is
-// an artefact of the heap's history (every accepted candidate, including ones evicted later).
-// ------------------------------------------------------------------------------------------
-template <int S>
-struct HeapCol {
-    float *keys;          // column base: element s at keys[s * S]
-    unsigned short *idx;
-    __device__ __forceinline__ float key(int s) const { return keys[s * S]; }
-    __device__ __forceinline__ void move(int dst, int src) const {
-        keys[dst * S] = keys[src * S];
-        idx[dst * S] = idx[src * S];
-    }
-    __device__ __forceinline__ void set(int s, float k, unsigned short r) const {
-        keys[s * S] = k;
-        idx[s * S] = r;
-    }
-    // __push_heap, src/binary_heap.hpp:34-45
-    __device__ __forceinline__ void push(int hole, int top, float xk, unsigned short xi) const {
-        int parent = (hole - 1) / 2;
-        while (hole > top && key(parent) < xk) {
-            move(hole, parent);
-            hole = parent;
-            parent = (hole - 1) / 2;
-        }
-        set(hole, xk, xi);
-    }
-    // __adjust_heap with comparator, src/binary_heap.hpp:112-130
-    __device__ __forceinline__ void adjust(int hole, int len, float xk, unsigned short xi) const {
-        const int top = hole;
-        int second = 2 * hole + 2;
-        while (second < len) {
-            if (key(second) < key(second - 1)) second--;
-            move(hole, second);
-            hole = second;
-            second = 2 * (second + 1);
-        }
-        if (second == len) {
-            move(hole, second - 1);
-            hole = second - 1;
-        }
-        push(hole, top, xk, xi);
-    }
-};
-
-constexpr int ROAD_TILE = 256;
-
-template <int A_T>
-__global__ __launch_bounds__(A_T) void k_map_obs(DevSim d) {
-    const int w = blockIdx.x, a = threadIdx.x;
-    const int n = d.shape[w * 2 + 0];
-    const int r0 = d.road_off[w];
-    const int R = d.road_off[w + 1] - r0;
-    const bool live = a < n;
-    const size_t i = (size_t)w * A_T + a;
-
-    __shared__ float s_keys[K * A_T];
-    __shared__ unsigned short s_idx[K * A_T];
-    __shared__ float2 s_tile[ROAD_TILE];
-    __shared__ float s_ex[A_T], s_ey[A_T], s_ew[A_T], s_ez[A_T];
-    __shared__ int s_count[A_T];
-
-    float ex = 0.f, ey = 0.f;
-    Quat inv{1.f, 0.f, 0.f, 0.f};
-    if (live) {
-        ex = d.px[i]; ey = d.py[i];
-        const float qw = d.qw[i], qz = d.qz[i];
-        inv = quat_inv(quat_from_wz(qw, qz));
-        s_ex[a] = ex; s_ey[a] = ey; s_ew[a] = qw; s_ez[a] = qz;
-    }
-    const HeapCol<A_T> heap{s_keys + a, s_idx + a};
-    const float radius = d.p.observationRadius;
-    const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
-    int count = 0;  // rows kept (newBeyond / arrIndex)
-
-    for (int base = 0; base < R; base += ROAD_TILE) {
-        const int tn = min(ROAD_TILE, R - base);
-        __syncthreads();
-        for (int t = a; t < tn; t += A_T) s_tile[t] = d.road_xy[(size_t)r0 + base + t];
-        __syncthreads();
-        if (!live) continue;
-        if (knn) {
-            for (int t = 0; t < tn; t++) {
-                const int r = base + t;
-                const float2 xy = s_tile[t];
-                const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                const float key = len2_2(rel.x, rel.y);
-                if (r < K) {
-                    heap.set(r, key, (unsigned short)r);
-                    if (r == K - 1) {  // make_heap, src/binary_heap.hpp:170-185
-                        for (int parent = (K - 2) / 2; parent >= 0; parent--)
-                            heap.adjust(parent, K, heap.key(parent), heap.idx[parent * A_T]);
-                    }
-                } else if (key < heap.key(0)) {
-                    // pop_heap + replace last + push_heap, src/knn.hpp:138-151
-                    const float lk = heap.key(K - 1);
-                    const unsigned short li = heap.idx[(K - 1) * A_T];
-                    heap.move(K - 1, 0);
-                    heap.adjust(0, K - 1, lk, li);
-                    heap.push(K - 1, 0, key, (unsigned short)r);
-                }
-            }
-        } else {
-            // AllEntitiesWithRadiusFiltering: first K in index order within the radius, sim.cpp:261-279
-            for (int t = 0; t < tn && count < K; t++) {
-                const float2 xy = s_tile[t];
-                const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                if (len_2(rel.x, rel.y) > radius) continue;
-                s_idx[count * A_T + a] = (unsigned short)(base + t);
-                count++;
-            }
-        }
-    }
-
-    if (live) {
-        if (knn) {
-            // radiusFilter, src/knn.hpp:83-97 (swap-remove in heap-array order)
-            int beyond = min(R, K), s = 0;
-            while (s < beyond) {
-                if (sqrtf(heap.key(s)) <= radius) { ++s; continue; }
-                --beyond;
-                heap.move(s, beyond);
-            }
-            count = beyond;
-        }
-        s_count[a] = count;
-    }
-    __syncthreads();
-
-    // Row write-out: one thread per (agent, slot); a wave writes 64 consecutive 36-byte rows.
-    const int rows = n * K;
-    float *out = d.agent_map + (size_t)w * A_T * K * 9;
-    for (int p = a; p < rows; p += A_T) {
-        const int ego = p / K, s = p - ego * K;
-        float *o = out + (size_t)p * 9;
-        if (s >= s_count[ego]) {
-            // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
-            // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
-            const float pad = knn ? 0.f : -1.f;
-            o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = (float)ET_None; o[7] = pad; o[8] = pad;
-            continue;
-        }
-        const int r = r0 + s_idx[s * A_T + ego];
-        const float2 xy = d.road_xy[r];
-        const float4 a0 = d.road_aux[(size_t)r * 2], a1 = d.road_aux[(size_t)r * 2 + 1];
-        const Quat einv = quat_inv(quat_from_wz(s_ew[ego], s_ez[ego]));
-        const V2 rel = ego_relative(s_ex[ego], s_ey[ego], einv, xy.x, xy.y);
-        o[0] = rel.x; o[1] = rel.y;
-        o[2] = a0.z; o[3] = a0.w; o[4] = a1.x;
-        o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(a0.x, a0.y)));
-        o[6] = a1.y; o[7] = a1.z; o[8] = a1.w;
-    }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -594,7 +440,7 @@ static void launch_all(const DevSim &d, hipStream_t st, int which, bool move) {
         if (move) hipLaunchKernelGGL((k_world_step<A_T, true>), grid, block, 0, st, d);
         else hipLaunchKernelGGL((k_world_step<A_T, false>), grid, block, 0, st, d);
         break;
-    case KERNEL_MAP_OBS: hipLaunchKernelGGL(k_map_obs<A_T>, grid, block, 0, st, d); break;
+    case KERNEL_MAP_OBS: launch_map_obs(d, st); break;
     }
 }
 

@@ -1,0 +1,377 @@
+// Road observations: collectMapObservationsSystem (reference src/sim.cpp:242-280) with
+// selectKNearestRoadEntities (src/knn.hpp:103-158) on the SGI heap (src/binary_heap.hpp).
+//
+// The output row ORDER of the reference is an artefact of the heap's history: every candidate
+// that was ever closer than the running K-th distance is pushed, including ones evicted later,
+// and the final array layout depends on all of them.  It cannot be recovered from the final
+// top-K set, so the kernel replays the exact insert sequence per agent:
+//
+//   * one 200-entry heap per agent in LDS, slot-major (keys[slot][agent]) so that an agent's
+//     lane always hits its own bank whatever slot it touches;
+//   * a workgroup per world, NW waves, each wave owning 64/G agents with G lanes per agent;
+//   * SCAN (all 64 lanes): roads are processed in windows of 14 x 32; each 32-road chunk is staged
+//     in a per-wave LDS tile (one coalesced load; road bytes reach HBM once per world, L2 serves
+//     the other waves), every lane tests its share of the chunk against the agent's K-th distance
+//     at the window start (a conservative superset of the true inserts), and a ballot folds the
+//     results into one candidate bit-mask word per (agent, chunk), in road order;
+//   * DRAIN (one lane per agent): each agent walks the set bits of its window masks at its own
+//     pace, re-tests the candidate against the live heap top and replays the reference's
+//     pop_heap / push_heap.  Long windows even out the candidate counts of the lanes of a wave
+//     (road polylines are spatially coherent: per 32-road chunk the busiest agent has ~8x the
+//     mean), which is what bounds the replay.
+//
+// The wave never synchronises with the other waves of the workgroup until the final write-out.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "engine.hpp"
+#include "gd_math.hpp"
+
+namespace gd {
+
+namespace {
+
+constexpr int K = GD_MAP_OBS_K;
+
+template <int S>
+struct HeapCol {
+    float *keys;          // column base: element s at keys[s * S]
+    unsigned short *idx;
+    __device__ __forceinline__ float key(int s) const { return keys[s * S]; }
+    __device__ __forceinline__ unsigned short index(int s) const { return idx[s * S]; }
+    __device__ __forceinline__ void move(int dst, int src) const {
+        keys[dst * S] = keys[src * S];
+        idx[dst * S] = idx[src * S];
+    }
+    __device__ __forceinline__ void set(int s, float k, unsigned short r) const {
+        keys[s * S] = k;
+        idx[s * S] = r;
+    }
+    // __push_heap, src/binary_heap.hpp:34-45.  Key and index of the parent are fetched together so
+    // that each level costs one LDS round trip.
+    __device__ __forceinline__ void push(int hole, int top, float xk, unsigned short xi) const {
+        int parent = (hole - 1) / 2;
+        while (hole > top) {
+            const float pk = key(parent);
+            const unsigned short pi = index(parent);
+            if (!(pk < xk)) break;
+            set(hole, pk, pi);
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        set(hole, xk, xi);
+    }
+    // __adjust_heap with comparator, src/binary_heap.hpp:112-130.  Both children (key + index) are
+    // fetched in one batch per level; the stores need no wait, so the dependent chain is one LDS
+    // round trip per level.
+    __device__ __forceinline__ void adjust(int hole, int len, float xk, unsigned short xi) const {
+        const int top = hole;
+        int second = 2 * hole + 2;
+        while (second < len) {
+            const float kr = key(second), kl = key(second - 1);
+            const unsigned short ir = index(second), il = index(second - 1);
+            const bool left = kr < kl;
+            set(hole, left ? kl : kr, left ? il : ir);
+            second -= left ? 1 : 0;
+            hole = second;
+            second = 2 * (second + 1);
+        }
+        if (second == len) {
+            move(hole, second - 1);
+            hole = second - 1;
+        }
+        push(hole, top, xk, xi);
+    }
+    // make_heap, src/binary_heap.hpp:170-185, serial form
+    __device__ __forceinline__ void make(int len) const {
+        for (int parent = (len - 2) / 2; parent >= 0; parent--) adjust(parent, len, key(parent), index(parent));
+    }
+    // make_heap with `g` cooperating lanes (this lane is number `sub`).  The reference sifts parents
+    // 99, 98, ..., 0 in turn; parents on one tree level own disjoint subtrees, so they commute and
+    // can be sifted concurrently, level by level from the bottom, with the identical result.
+    // Callers put a wave_sync() between levels (see k_map_obs).
+    __device__ __forceinline__ void make_level(int len, int depth, int sub, int g) const {
+        const int first = (1 << depth) - 1;
+        const int last = min((2 << depth) - 2, (len - 2) / 2);
+        for (int parent = first + sub; parent <= last; parent += g) adjust(parent, len, key(parent), index(parent));
+    }
+    // pop_heap + replace last + push_heap, src/knn.hpp:138-151
+    __device__ __forceinline__ void replace_top(float xk, unsigned short xi) const {
+        const float lk = key(K - 1);
+        const unsigned short li = index(K - 1);
+        move(K - 1, 0);
+        adjust(0, K - 1, lk, li);
+        push(K - 1, 0, xk, xi);
+    }
+    // radiusFilter, src/knn.hpp:83-97 (swap-remove in heap-array order); returns newBeyond
+    __device__ __forceinline__ int radius_filter(int len, float radius) const {
+        int beyond = len, s = 0;
+        while (s < beyond) {
+            if (sqrtf(key(s)) <= radius) { ++s; continue; }
+            --beyond;
+            move(s, beyond);
+        }
+        return beyond;
+    }
+};
+
+// Intra-wave ordering point for LDS traffic between lanes of one wave.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Row write-out shared by both implementations: one thread per (agent, slot); a wave writes 64
+// consecutive 36-byte rows.
+template <int A_T>
+__device__ __forceinline__ void write_rows(const DevSim &d, int w, int n, int r0, bool knn, const unsigned short *s_idx,
+                                           const int *s_count, int tid, int nthreads) {
+    const int rows = n * K;
+    float *out = d.agent_map + (size_t)w * A_T * K * 9;
+    for (int p = tid; p < rows; p += nthreads) {
+        const int ego = p / K, s = p - ego * K;
+        float *o = out + (size_t)p * 9;
+        if (s >= s_count[ego]) {
+            // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
+            // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
+            const float pad = knn ? 0.f : -1.f;
+            o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = (float)ET_None; o[7] = pad; o[8] = pad;
+            continue;
+        }
+        const size_t ei = (size_t)w * A_T + ego;
+        const int r = r0 + s_idx[s * A_T + ego];
+        const float2 xy = d.road_xy[r];
+        const float4 a0 = d.road_aux[(size_t)r * 2], a1 = d.road_aux[(size_t)r * 2 + 1];
+        const Quat einv = quat_inv(quat_from_wz(d.qw[ei], d.qz[ei]));
+        const V2 rel = ego_relative(d.px[ei], d.py[ei], einv, xy.x, xy.y);
+        o[0] = rel.x; o[1] = rel.y;
+        o[2] = a0.z; o[3] = a0.w; o[4] = a1.x;
+        o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(a0.x, a0.y)));
+        o[6] = a1.y; o[7] = a1.z; o[8] = a1.w;
+    }
+}
+
+// ---- v2: NW waves per world, G lanes per agent, windowed candidate masks ----
+template <int A_T, int NW, int WW>
+__global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
+    constexpr int C = 32;          // roads per chunk = one mask word
+    constexpr int APW = A_T / NW;  // agents per wave
+    constexpr int G = 64 / APW;    // lanes per agent
+    static_assert(APW * NW == A_T && APW * G == 64 && C % G == 0, "geometry");
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int al = lane % APW, sub = lane / APW;
+    const int a = wave * APW + al;
+    const int n = d.shape[w * 2 + 0];
+    const int r0 = d.road_off[w];
+    const int R = d.road_off[w + 1] - r0;
+    const bool live = a < n;
+    const size_t i = (size_t)w * A_T + a;
+
+    __shared__ float s_keys[K * A_T];
+    __shared__ unsigned short s_idx[K * A_T];
+    __shared__ unsigned int s_mask[WW * A_T];  // word c of agent a at [c * A_T + a]: candidate bits of chunk c
+    __shared__ float2 s_tile[NW][C];
+    __shared__ int s_count[A_T];
+
+    const float radius = d.p.observationRadius;
+    const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
+    const HeapCol<A_T> heap{s_keys + a, s_idx + a};
+    int count = 0;
+
+    if (wave * APW < n) {  // wave-uniform: waves without live agents skip the scan
+        float ex = 0.f, ey = 0.f;
+        Quat inv{1.f, 0.f, 0.f, 0.f};
+        if (live) {
+            ex = d.px[i]; ey = d.py[i];
+            inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
+        }
+        float2 *tile = s_tile[wave];
+        // bits of this agent's G lanes inside a ballot -> G contiguous bits (road order)
+        auto agent_bits = [&](bool pass) -> unsigned int {
+            const unsigned long long m = __ballot(pass) >> al;
+            unsigned int bits = 0;
+#pragma unroll
+            for (int g = 0; g < G; g++) bits |= (unsigned int)((m >> (g * APW)) & 1ull) << g;
+            return bits;
+        };
+        const unsigned int below = (1u << sub) - 1u;
+
+        for (int win = 0; win < R; win += WW * C) {
+            const int win_end = min(R, win + WW * C);
+            float thr = (live && win >= K) ? heap.key(0) : -1.f;
+            // ---- SCAN: all lanes; one mask word per 32-road chunk ----
+            for (int base = win, c = 0; base < win_end; base += C, c++) {
+                const int tn = min(C, R - base);
+                wave_sync();
+                if (lane < tn) tile[lane] = d.road_xy[(size_t)r0 + base + lane];
+                wave_sync();
+                unsigned int word = 0;
+                if (knn) {
+                    // roads with index < K go straight into the array (src/knn.hpp:112-120)
+                    const int direct_end = min(tn, max(0, K - base));
+                    for (int t = sub; t < direct_end; t += G) {
+                        if (live) {
+                            const float2 xy = tile[t];
+                            const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                            heap.set(base + t, len2_2(rel.x, rel.y), (unsigned short)(base + t));
+                        }
+                    }
+                    if (direct_end > 0 && base + direct_end == K) {
+                        for (int depth = 6; depth >= 0; depth--) {  // parents 0..99 live on levels 0..6
+                            wave_sync();
+                            if (live) heap.make_level(K, depth, sub, G);
+                        }
+                        wave_sync();
+                        thr = live ? heap.key(0) : -1.f;
+                    }
+                    // conservative candidates: closer than the K-th distance at the window start
+                    for (int t0 = direct_end; t0 < tn; t0 += G) {
+                        const int t = t0 + sub;
+                        bool pass = false;
+                        if (live && t < tn) {
+                            const float2 xy = tile[t];
+                            const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                            pass = len2_2(rel.x, rel.y) < thr;
+                        }
+                        word |= agent_bits(pass) << t0;
+                    }
+                    if (sub == 0) s_mask[c * A_T + a] = word;
+                } else {
+                    // AllEntitiesWithRadiusFiltering: first K in index order within the radius, sim.cpp:261-279
+                    for (int t0 = 0; t0 < tn; t0 += G) {
+                        const int t = t0 + sub;
+                        bool pass = false;
+                        if (live && t < tn) {
+                            const float2 xy = tile[t];
+                            const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                            pass = !(len_2(rel.x, rel.y) > radius);
+                        }
+                        const unsigned int bits = agent_bits(pass);
+                        const int pos = count + __popc(bits & below);
+                        if (pass && pos < K) s_idx[pos * A_T + a] = (unsigned short)(base + t);
+                        count += __popc(bits);
+                    }
+                }
+            }
+            // ---- DRAIN: one lane per agent replays its candidates of this window in road order ----
+            if (knn && win_end > K) {
+                wave_sync();
+                if (live && sub == 0 && !(d.debug_flags & 2)) {
+                    const int nwords = (win_end - win + C - 1) / C;
+                    int c = 0;
+                    unsigned int word = s_mask[a];
+                    for (;;) {
+                        while (word == 0 && ++c < nwords) word = s_mask[c * A_T + a];
+                        if (word == 0) break;
+                        const int b = __ffs(word) - 1;
+                        word &= word - 1;
+                        const int r = win + c * C + b;
+                        const float2 xy = d.road_xy[(size_t)r0 + r];
+                        const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                        const float key = len2_2(rel.x, rel.y);
+                        if (key < heap.key(0)) heap.replace_top(key, (unsigned short)r);
+                    }
+                }
+            }
+        }
+        wave_sync();
+        if (live && sub == 0) {
+            if (knn) count = heap.radius_filter(min(R, K), radius);
+            s_count[a] = min(count, K);
+        }
+    }
+    __syncthreads();
+    if (d.debug_flags & 1) return;
+    write_rows<A_T>(d, w, n, r0, knn, s_idx, s_count, tid, NW * 64);
+}
+
+// ---- v1 (kept for A/B runs, GPUDRIVE_MAP_OBS_IMPL=1): one lane per agent, heap op under the scan ----
+constexpr int ROAD_TILE = 256;
+
+template <int A_T>
+__global__ __launch_bounds__(A_T) void k_map_obs_v1(DevSim d) {
+    const int w = blockIdx.x, a = threadIdx.x;
+    const int n = d.shape[w * 2 + 0];
+    const int r0 = d.road_off[w];
+    const int R = d.road_off[w + 1] - r0;
+    const bool live = a < n;
+    const size_t i = (size_t)w * A_T + a;
+
+    __shared__ float s_keys[K * A_T];
+    __shared__ unsigned short s_idx[K * A_T];
+    __shared__ float2 s_tile[ROAD_TILE];
+    __shared__ int s_count[A_T];
+
+    float ex = 0.f, ey = 0.f;
+    Quat inv{1.f, 0.f, 0.f, 0.f};
+    if (live) {
+        ex = d.px[i]; ey = d.py[i];
+        inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
+    }
+    const HeapCol<A_T> heap{s_keys + a, s_idx + a};
+    const float radius = d.p.observationRadius;
+    const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
+    int count = 0;
+
+    for (int base = 0; base < R; base += ROAD_TILE) {
+        const int tn = min(ROAD_TILE, R - base);
+        __syncthreads();
+        for (int t = a; t < tn; t += A_T) s_tile[t] = d.road_xy[(size_t)r0 + base + t];
+        __syncthreads();
+        if (!live) continue;
+        if (knn) {
+            for (int t = 0; t < tn; t++) {
+                const int r = base + t;
+                const float2 xy = s_tile[t];
+                const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                const float key = len2_2(rel.x, rel.y);
+                if (r < K) {
+                    heap.set(r, key, (unsigned short)r);
+                    if (r == K - 1) heap.make(K);
+                } else if (key < heap.key(0)) {
+                    heap.replace_top(key, (unsigned short)r);
+                }
+            }
+        } else {
+            for (int t = 0; t < tn && count < K; t++) {
+                const float2 xy = s_tile[t];
+                const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                if (len_2(rel.x, rel.y) > radius) continue;
+                s_idx[count * A_T + a] = (unsigned short)(base + t);
+                count++;
+            }
+        }
+    }
+    if (live) {
+        if (knn) count = heap.radius_filter(min(R, K), radius);
+        s_count[a] = count;
+    }
+    __syncthreads();
+    write_rows<A_T>(d, w, n, r0, knn, s_idx, s_count, a, A_T);
+}
+
+int map_obs_impl() {
+    static const int impl = []() {
+        const char *e = std::getenv("GPUDRIVE_MAP_OBS_IMPL");
+        return e ? std::atoi(e) : 2;
+    }();
+    return impl;
+}
+
+}  // namespace
+
+void launch_map_obs(const DevSim &d, hipStream_t st) {
+    const dim3 grid(d.W);
+    if (map_obs_impl() == 1) {
+        if (d.A == 64) hipLaunchKernelGGL(k_map_obs_v1<64>, grid, dim3(64), 0, st, d);
+        else hipLaunchKernelGGL(k_map_obs_v1<128>, grid, dim3(128), 0, st, d);
+        return;
+    }
+    if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64, 4, 14>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((k_map_obs<128, 8, 14>), grid, dim3(512), 0, st, d);
+}
+
+}  // namespace gd

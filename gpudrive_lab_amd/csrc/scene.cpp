@@ -2,6 +2,7 @@
 #include "scene.hpp"
 
 #include <algorithm>
+#include <cfloat>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -453,6 +454,52 @@ void build_host_world(const SceneMap &map, const gd_params &p, int A, const int3
             put_road(w, r.pts[0] - w.mean[0], r.pts[1] - w.mean[1], quat_yaw(0.f), 0.2f, 0.2f, 1.f, ET_StopSign, r.id,
                      r.map_type);
         }
+    }
+
+    // Broadphase grid.  A box belongs to a cell if its centre is within (box radius + largest agent
+    // radius, both with the kernels' 1.001 / +0.01 slack) of the cell's square, so the per-pair
+    // bounding-circle test in the kernel never sees fewer boxes than a full scan would.
+    if (!w.boxes.empty()) {
+        float max_agent_r = 0.f;
+        for (int i = 0; i < w.num_agents; i++)
+            max_agent_r = std::max(max_agent_r, sqrtf(w.scale[i * 2] * w.scale[i * 2] + w.scale[i * 2 + 1] * w.scale[i * 2 + 1]));
+        float minx = FLT_MAX, miny = FLT_MAX, maxx = -FLT_MAX, maxy = -FLT_MAX, max_r = 0.f;
+        for (const RoadBox &b : w.boxes) {
+            minx = std::min(minx, b.cx); maxx = std::max(maxx, b.cx);
+            miny = std::min(miny, b.cy); maxy = std::max(maxy, b.cy);
+            max_r = std::max(max_r, b.radius);
+        }
+        const float reach_pad = (max_agent_r + max_r) * 1.002f + 0.05f;
+        minx -= reach_pad; miny -= reach_pad; maxx += reach_pad; maxy += reach_pad;
+        const float extent = std::max(maxx - minx, maxy - miny);
+        const float cell = std::max(16.f, extent / 64.f);
+        w.grid_ox = minx; w.grid_oy = miny; w.grid_cell = cell;
+        w.grid_nx = std::max(1, static_cast<int>(std::ceil((maxx - minx) / cell)));
+        w.grid_ny = std::max(1, static_cast<int>(std::ceil((maxy - miny) / cell)));
+        const int ncell = w.grid_nx * w.grid_ny;
+        std::vector<std::vector<int32_t>> lists(ncell);
+        for (size_t bi = 0; bi < w.boxes.size(); bi++) {
+            const RoadBox &b = w.boxes[bi];
+            const float reach = (max_agent_r + b.radius) * 1.002f + 0.05f;
+            const int x0 = std::max(0, static_cast<int>(std::floor((b.cx - reach - minx) / cell)) - 1);
+            const int x1 = std::min(w.grid_nx - 1, static_cast<int>(std::floor((b.cx + reach - minx) / cell)) + 1);
+            const int y0 = std::max(0, static_cast<int>(std::floor((b.cy - reach - miny) / cell)) - 1);
+            const int y1 = std::min(w.grid_ny - 1, static_cast<int>(std::floor((b.cy + reach - miny) / cell)) + 1);
+            for (int y = y0; y <= y1; y++)
+                for (int x = x0; x <= x1; x++) {
+                    const float qx0 = minx + x * cell, qy0 = miny + y * cell;
+                    const float dx = std::max(std::max(qx0 - b.cx, 0.f), b.cx - (qx0 + cell));
+                    const float dy = std::max(std::max(qy0 - b.cy, 0.f), b.cy - (qy0 + cell));
+                    if (dx * dx + dy * dy <= reach * reach) lists[y * w.grid_nx + x].push_back(static_cast<int32_t>(bi));
+                }
+        }
+        w.cell_off.assign(ncell + 1, 0);
+        for (int c = 0; c < ncell; c++) w.cell_off[c + 1] = w.cell_off[c] + static_cast<int32_t>(lists[c].size());
+        w.cell_items.reserve(w.cell_off[ncell]);
+        for (int c = 0; c < ncell; c++) w.cell_items.insert(w.cell_items.end(), lists[c].begin(), lists[c].end());
+    } else {
+        w.grid_nx = w.grid_ny = 0;
+        w.cell_off.assign(1, 0);
     }
 }
 

@@ -80,6 +80,13 @@ struct HostWorld {
     std::vector<float> road_xy;      // [num_roads][2]
     std::vector<float> road_aux;     // [num_roads][8] qw,qz,d0,d1,d2,type,id,mapType
     std::vector<RoadBox> boxes;      // collidable subset
+    // uniform broadphase grid over the collidable boxes (stands in for Madrona's BVH,
+    // reference src/sim.cpp:792-797): cell c lists every box whose bounding circle can touch an
+    // agent whose centre lies in c
+    float grid_ox = 0, grid_oy = 0, grid_cell = 1;
+    int grid_nx = 0, grid_ny = 0;
+    std::vector<int32_t> cell_off;   // [nx*ny + 1]
+    std::vector<int32_t> cell_items; // local box indices
 };
 
 void build_host_world(const SceneMap &map, const gd_params &params, int max_agents,
