@@ -55,7 +55,7 @@ def scenes_for(workload, worlds, rank):
     return sharding.scene_list_for_rank(WAYMO, worlds, rank)
 
 
-def make_sim(scenes, kw, agents, device_index):
+def make_sim(scenes, kw, agents, device_index, knn_order=0):
     import madrona_gpudrive as mg
     p = mg.Parameters()
     for k, v in kw.items():
@@ -64,7 +64,7 @@ def make_sim(scenes, kw, agents, device_index):
         else:
             setattr(p, k, v)
     return mg.SimManager(exec_mode=mg.madrona.ExecMode.CUDA, gpu_id=device_index, scenes=scenes, params=p,
-                         max_agents=agents)
+                         max_agents=agents, knn_order=knn_order)
 
 
 def action_batches(worlds, agents, device, seed, n=8):
@@ -92,7 +92,7 @@ def bench_workload(workload, args, rank, local_rank, world, device):
     kw = params_for(workload)
     scenes = scenes_for(workload, args.worlds, rank)
     t0 = time.time()
-    sim = make_sim(scenes, kw, args.agents, local_rank)
+    sim = make_sim(scenes, kw, args.agents, local_rank, knn_order=args.knn_order)
     torch.cuda.synchronize(device)
     init_s = time.time() - t0
     shape = sim.shape_tensor().to_torch().cpu().numpy()
@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=40)
     ap.add_argument("--workloads", default="synthetic,waymo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--knn-order", type=int, default=0, choices=(0, 1),
+                    help="0 = reference heap order (default, elementwise parity); 1 = same row set, road-index order")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -222,9 +224,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%d worlds x %d agents per GPU, classic bicycle dynamics, %d-partner + 200-road-point "
-                            "k-NN obs (reference heap order), radius 50, collisions ignored, reset every 91 steps; "
+                            "k-NN obs (%s), radius 50, collisions ignored, reset every 91 steps; "
                             "scenes: seeded synthetic exact-64 (64 live agents, 4096 road-edge segments per world)"
-                            % (args.worlds, args.agents, args.agents - 1),
+                            % (args.worlds, args.agents, args.agents - 1,
+                               "reference heap order" if args.knn_order == 0 else "SET order: same rows, road-index order"),
                 "worlds_per_gpu": args.worlds, "max_agents": args.agents,
                 "parallelism": "worlds sharded %d-way, no per-step collective" % world,
             },

@@ -27,6 +27,7 @@ struct GridHdr {
 //   collidable boxes : CSR over worlds; 5 x float4 per box {cx,cy,radius,type | 14-float OBB}
 struct DevSim {
     int W, A;
+    int knn_order;    // GD_KNN_*
     int debug_flags;  // developer ablation switches (GPUDRIVE_DEBUG_FLAGS), 0 in production
     gd_params p;
     // exported
@@ -46,6 +47,8 @@ struct DevSim {
     const float4 *road_aux;
     const int32_t *box_off;   // [W+1]
     const float4 *boxes;
+    unsigned int *mask_scratch; // [W][mask_nch][A]: candidate bits of the road-observation kernel
+    int mask_nch;               // 32-road chunks per world (max over worlds)
     const GridHdr *grid;        // [W]
     const int32_t *cell_off;    // per world nx*ny+1 entries, local offsets
     const int32_t *cell_items;  // local box indices

@@ -288,6 +288,169 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
     write_rows<A_T>(d, w, n, r0, knn, s_idx, s_count, tid, NW * 64);
 }
 
+// ---- set-order mode (gd_config.knn_order = GD_KNN_SET_ORDER) ----
+//
+// Same row SET as the reference (the K nearest by (distance^2, road index), then the radius filter),
+// rows in ascending road index instead of the reference's heap-history order.  Because the radius
+// filter runs after the top-K, the result is simply "every in-radius road" whenever at most K roads
+// are in radius, and the K smallest of the in-radius roads otherwise; no heap is needed, so the
+// kernel is one streaming pass: scanner waves build in-radius bit-masks (chunk x agent words in an
+// L2-resident scratch), each agent lane compacts its set bits, and the rare agents with more than K
+// in-radius roads get an exact block-cooperative selection by bisection on the key bits.
+template <int A_T, int NW>
+__global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
+    constexpr int DW = A_T / 64;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int n = d.shape[w * 2 + 0];
+    const int r0 = d.road_off[w];
+    const int R = d.road_off[w + 1] - r0;
+    const float radius = d.p.observationRadius;
+    const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
+
+    constexpr int CAP = 1024;  // in-radius candidates a wave can hold in LDS
+    __shared__ unsigned short s_idx[K * A_T];
+    __shared__ int s_count[A_T];
+    __shared__ float s_ckey[NW][CAP];
+    __shared__ unsigned short s_cidx[NW][CAP];
+
+    unsigned int *mask = d.mask_scratch + (size_t)w * d.mask_nch * A_T;
+    const int nchunks = (R + 31) / 32;
+
+    // in-radius masks: wave `wave` takes tasks (chunk, agent group) round-robin; lane = agent
+    for (int task = wave; task < nchunks * DW; task += NW) {
+        const int c = task / DW, a = (task % DW) * 64 + lane;
+        const int rb = c * 32;
+        const int rl = rb + (lane & 31);
+        float2 v = make_float2(0.f, 0.f);
+        if (rl < R) v = d.road_xy[(size_t)r0 + rl];
+        float ex = 0.f, ey = 0.f;
+        Quat inv{1.f, 0.f, 0.f, 0.f};
+        const bool live = a < n;
+        if (live) {
+            const size_t i = (size_t)w * A_T + a;
+            ex = d.px[i]; ey = d.py[i];
+            inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
+        }
+        unsigned int word = 0;
+#pragma unroll
+        for (int t = 0; t < 32; t++) {
+            const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), t));
+            const float y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.y), t));
+            const V2 rel = ego_relative(ex, ey, inv, x, y);
+            // radiusFilter keeps length() <= radius (src/knn.hpp:88); the linear scan skips length() > radius
+            const bool pass = knn ? (sqrtf(len2_2(rel.x, rel.y)) <= radius) : !(len_2(rel.x, rel.y) > radius);
+            word |= (pass ? 1u : 0u) << t;
+        }
+        if (rb + 32 > R) word &= (1u << (R - rb)) - 1u;
+        if (!live) word = 0;
+        mask[(size_t)c * A_T + a] = word;
+    }
+    __syncthreads();
+
+    // selection: each wave takes its agents one at a time, all 64 lanes cooperating
+    constexpr int APW = A_T / NW;
+    float *ckey = s_ckey[wave];
+    unsigned short *cidx = s_cidx[wave];
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    for (int al = 0; al < APW; al++) {
+        const int a = wave * APW + al;
+        if (a >= n) break;  // wave-uniform
+        const size_t i = (size_t)w * A_T + a;
+        const float ex = d.px[i], ey = d.py[i];
+        const Quat inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
+        // gather the in-radius candidates (key, road) in road order
+        int nin = 0;
+        for (int rb = 0; rb < R; rb += 64) {
+            const unsigned int w0 = mask[(size_t)(rb >> 5) * A_T + a];
+            const unsigned int w1 = (rb + 32 < R) ? mask[(size_t)((rb >> 5) + 1) * A_T + a] : 0u;
+            if ((w0 | w1) == 0u) continue;  // wave-uniform
+            const int r = rb + lane;
+            const bool in = ((lane < 32 ? w0 : w1) >> (lane & 31)) & 1u;
+            float key = 0.f;
+            if (in) {
+                const float2 xy = d.road_xy[(size_t)r0 + r];
+                const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                key = len2_2(rel.x, rel.y);
+            }
+            const unsigned long long b = __ballot(in);
+            const int pos = nin + __popcll(b & lower);
+            if (in && pos < CAP) { ckey[pos] = key; cidx[pos] = (unsigned short)r; }
+            nin += __popcll(b);
+        }
+        wave_sync();
+        int count = 0;
+        if (nin <= K || !knn) {
+            // every in-radius road (k-NN), or the first K of them (linear scan), in road order
+            count = min(nin, K);
+            for (int j = lane; j < count; j += 64) s_idx[j * A_T + a] = cidx[j];
+        } else if (nin <= CAP) {
+            // K smallest by (key, road): bisection on the key bits for the K-th smallest key T
+            // (largest T with count(key < T) < K), then everything below T plus the earliest ties
+            unsigned int lo = 0u, hi = 0x7f800000u;
+            while (lo < hi) {
+                const unsigned int mid = lo + (hi - lo + 1) / 2;
+                int cnt = 0;
+                for (int j = lane; j < nin; j += 64) cnt += __float_as_uint(ckey[j]) < mid ? 1 : 0;
+                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+                if (cnt < K) lo = mid; else hi = mid - 1;
+            }
+            int less = 0;
+            for (int j = lane; j < nin; j += 64) less += __float_as_uint(ckey[j]) < lo ? 1 : 0;
+            for (int off = 32; off > 0; off >>= 1) less += __shfl_xor(less, off);
+            int need_ties = K - less;
+            for (int jb = 0; jb < nin; jb += 64) {
+                const int j = jb + lane;
+                const unsigned int kb = j < nin ? __float_as_uint(ckey[j]) : 0xffffffffu;
+                const bool tie = kb == lo;
+                const unsigned long long tb = __ballot(tie);
+                const bool take = kb < lo || (tie && __popcll(tb & lower) < need_ties);
+                need_ties -= min(need_ties, __popcll(tb));
+                const unsigned long long kb2 = __ballot(take);
+                if (take) s_idx[(count + __popcll(kb2 & lower)) * A_T + a] = cidx[j];
+                count += __popcll(kb2);
+            }
+        } else {
+            // more in-radius roads than the LDS candidate buffer holds: same selection, keys recomputed
+            // from the scratch masks on every bisection step
+            auto key_bits = [&](int r, bool &in) -> unsigned int {
+                in = r < R && ((mask[(size_t)(r >> 5) * A_T + a] >> (r & 31)) & 1u);
+                if (!in) return 0xffffffffu;
+                const float2 xy = d.road_xy[(size_t)r0 + r];
+                const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                return __float_as_uint(len2_2(rel.x, rel.y));
+            };
+            unsigned int lo = 0u, hi = 0x7f800000u;
+            while (lo < hi) {
+                const unsigned int mid = lo + (hi - lo + 1) / 2;
+                int cnt = 0;
+                for (int r = lane; r < R; r += 64) { bool in; cnt += key_bits(r, in) < mid ? 1 : 0; }
+                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+                if (cnt < K) lo = mid; else hi = mid - 1;
+            }
+            int less = 0;
+            for (int r = lane; r < R; r += 64) { bool in; less += key_bits(r, in) < lo ? 1 : 0; }
+            for (int off = 32; off > 0; off >>= 1) less += __shfl_xor(less, off);
+            int need_ties = K - less;
+            for (int rb = 0; rb < R; rb += 64) {
+                bool in;
+                const unsigned int kb = key_bits(rb + lane, in);
+                const bool tie = in && kb == lo;
+                const unsigned long long tb = __ballot(tie);
+                const bool take = (in && kb < lo) || (tie && __popcll(tb & lower) < need_ties);
+                need_ties -= min(need_ties, __popcll(tb));
+                const unsigned long long kb2 = __ballot(take);
+                if (take) s_idx[(count + __popcll(kb2 & lower)) * A_T + a] = (unsigned short)(rb + lane);
+                count += __popcll(kb2);
+            }
+        }
+        if (lane == 0) s_count[a] = min(count, K);
+        wave_sync();
+    }
+    __syncthreads();
+    write_rows<A_T>(d, w, n, r0, knn, s_idx, s_count, tid, NW * 64);
+}
+
 // ---- v1 (kept for A/B runs, GPUDRIVE_MAP_OBS_IMPL=1): one lane per agent, heap op under the scan ----
 constexpr int ROAD_TILE = 256;
 
@@ -368,6 +531,11 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
     if (map_obs_impl() == 1) {
         if (d.A == 64) hipLaunchKernelGGL(k_map_obs_v1<64>, grid, dim3(64), 0, st, d);
         else hipLaunchKernelGGL(k_map_obs_v1<128>, grid, dim3(128), 0, st, d);
+        return;
+    }
+    if (d.knn_order == GD_KNN_SET_ORDER) {
+        if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4>), grid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((k_map_obs_set<128, 8>), grid, dim3(512), 0, st, d);
         return;
     }
     if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64, 4, 14>), grid, dim3(256), 0, st, d);

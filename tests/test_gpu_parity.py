@@ -106,6 +106,43 @@ def test_lockstep_parity(oracle_mod, name, scenes, A, steps, kw):
     gpu.close()
 
 
+SET_ORDER = [
+    ("set_classic", [TEST_JSON, SCENE_407, SCENE_4], 64, 20,
+     dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+          distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)),
+    # unreduced polylines and a 100 m radius: far more than K roads in radius -> exact selection path
+    ("set_unreduced", [TEST_JSON], 64, 4,
+     dict(polylineReductionThreshold=0.0, observationRadius=100.0, collisionBehaviour=2, rewardType=1,
+          distanceToGoalThreshold=2.0, dynamicsModel=0, initOnlyValidAgentsAtFirstStep=0)),
+    ("set_fork128", [SCENE_4, SCENE_407], 128, 6,
+     dict(polylineReductionThreshold=0.0, observationRadius=60.0, collisionBehaviour=0, rewardType=1,
+          distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)),
+]
+
+
+@pytest.mark.parametrize("name,scenes,A,steps,kw", SET_ORDER, ids=[c[0] for c in SET_ORDER])
+def test_set_order_mode_matches_reference_rows_as_a_set(oracle_mod, name, scenes, A, steps, kw):
+    """gd_config.knn_order = GD_KNN_SET_ORDER: every other tensor identical, road rows equal to the
+    oracle's as a set (the reference's order is a heap-history artefact)."""
+    gpu = P.make_gpu_sim(scenes, max_agents=A, knn_order=1, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=A, **kw)
+    names = [n for n in P.OBS_TENSORS if n != "agent_roadmap_tensor"]
+    rng = np.random.default_rng(5)
+    for k in range(steps):
+        act = P.random_actions(rng, orc.W, orc.A, 0)
+        RC.write_actions(gpu, act)
+        np.copyto(orc.action_tensor(), act)
+        gpu.step()
+        orc.step()
+        P.compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+        gpu.debug_set_state(orc.get_state())
+        gpu.reset([])
+        orc.reset([])
+        P.compare_obs(gpu, orc, names=names)
+        P.compare_roadmap_as_set(gpu, orc)
+    gpu.close()
+
+
 def test_free_running_flags_stay_exact(oracle_mod):
     """No teacher forcing: 91 steps + reset + 30 steps; int tensors must stay bit-exact."""
     kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
