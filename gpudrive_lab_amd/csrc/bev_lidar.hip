@@ -1,0 +1,301 @@
+// BEV rasteriser (reference src/sim.cpp:462-555 + src/rasterizer.hpp) and LiDAR (src/sim.cpp:394-460).
+// One workgroup per live agent (grid = agents x worlds); both are opt-in (gd_config.alloc_bev,
+// Parameters.enableLidar).
+#include <hip/hip_runtime.h>
+
+#include "engine.hpp"
+#include "gd_math.hpp"
+
+namespace gd {
+
+namespace {
+
+constexpr int K = GD_MAP_OBS_K;
+constexpr int RES = GD_BEV_RES;
+
+// ------------------------------------------------------------------------------------------
+// BEV.  Entities are painted in the reference's order (first <= 200 in-radius roads in road order,
+// then in-radius partners in OtherAgents order; later paints overwrite earlier ones).  The grid
+// lives in LDS as one byte per cell; each of the 4 waves owns 50 grid rows and paints every entity
+// clipped to its rows, so paint order needs no barrier.
+// ------------------------------------------------------------------------------------------
+struct BevEnt {
+    float cx, cy, cosy, siny, half_l, half_w;
+    int gx, gy, br, type;
+};
+
+__device__ __forceinline__ BevEnt bev_entity(float cx, float cy, float yaw, float length, float width, int type,
+                                             float radius) {
+    // rasterizeRotatedRectangle prologue, src/rasterizer.hpp:27-50
+    BevEnt e;
+    e.cx = cx; e.cy = cy;
+    e.half_w = width / 2.0f;
+    e.half_l = length / 2.0f;
+    const float scale_px = (2 * radius) / RES;
+    const float scale_m = RES / (2 * radius);
+    int gx = (int)((cx + radius) * scale_m), gy = (int)((cy + radius) * scale_m);
+    e.gx = min(max(0, gx), RES - 1);
+    e.gy = min(max(0, gy), RES - 1);
+    const float max_side = fmaxf(e.half_w, e.half_l);
+    e.br = (int)ceilf(sqrtf(2 * (max_side * max_side)) / scale_px);
+    e.cosy = p_cos(-yaw);
+    e.siny = p_sin(-yaw);
+    e.type = type;
+    return e;
+}
+
+template <int A_T>
+__global__ __launch_bounds__(256) void k_bev(DevSim d) {
+    const int a = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const int n = d.shape[w * 2 + 0];
+    if (a >= n) return;  // rows of padding agents are never written (src/level_gen.cpp:308-336)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r0 = d.road_off[w];
+    const int R = d.road_off[w + 1] - r0;
+    const float radius = d.p.observationRadius;
+    const size_t i = (size_t)w * A_T + a;
+
+    constexpr int MAXE = K + GD_MAX_AGENTS_LIMIT;
+    __shared__ unsigned char s_grid[RES * RES];
+    __shared__ BevEnt s_ent[MAXE];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_ne;
+
+    const float ex = d.px[i], ey = d.py[i];
+    const Quat rot = quat_from_wz(d.qw[i], d.qz[i]);
+    const Quat inv = quat_inv(rot);
+
+    for (int c = tid; c < RES * RES / 4; c += 256) reinterpret_cast<unsigned int *>(s_grid)[c] = 0u;
+
+    // ---- roads: first K in-radius in road order (src/sim.cpp:484-523) ----
+    int count = 0;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    for (int base = 0; base < R && count < K; base += 256) {
+        const int r = base + tid;
+        bool in = false;
+        V2 rel{0.f, 0.f};
+        if (r < R) {
+            const float2 xy = d.road_xy[(size_t)r0 + r];
+            rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+            in = !(len_2(rel.x, rel.y) > radius);
+        }
+        const unsigned long long b = __ballot(in);
+        if (lane == 0) s_wcnt[wave] = __popcll(b);
+        __syncthreads();
+        int before = count;
+        for (int v = 0; v < wave; v++) before += s_wcnt[v];
+        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        const int pos = before + __popcll(b & lower);
+        if (in && pos < K) {
+            const float4 a0 = d.road_aux[(size_t)(r0 + r) * 2], a1 = d.road_aux[(size_t)(r0 + r) * 2 + 1];
+            const float yaw = quat_to_yaw(quat_mul(inv, quat_from_wz(a0.x, a0.y)));
+            const float minw = (2 * radius / RES);
+            s_ent[pos] = bev_entity(rel.x, rel.y, yaw, a0.z, fmaxf(a0.w, minw), (int)(size_t)a1.y, radius);
+        }
+        count = min(count + total, K);
+        __syncthreads();
+    }
+    // ---- partners in OtherAgents order (src/sim.cpp:526-554) ----
+    {
+        const int j = tid;  // A_T <= 128 < 256
+        bool in = false;
+        V2 rel{0.f, 0.f};
+        if (j < n && j != a) {
+            const size_t oi = (size_t)w * A_T + j;
+            rel = ego_relative(ex, ey, inv, d.px[oi], d.py[oi]);
+            in = !(len_2(rel.x, rel.y) > radius);
+        }
+        const unsigned long long b = __ballot(in);
+        if (lane == 0) s_wcnt[wave] = __popcll(b);
+        __syncthreads();
+        int before = count;
+        for (int v = 0; v < wave; v++) before += s_wcnt[v];
+        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (in) {
+            const size_t oi = (size_t)w * A_T + j;
+            const float yaw = quat_to_yaw(quat_mul(inv, quat_from_wz(d.qw[oi], d.qz[oi])));
+            s_ent[before + __popcll(b & lower)] = bev_entity(rel.x, rel.y, yaw, d.len[oi], d.wid[oi], d.etype[oi], radius);
+        }
+        if (tid == 0) s_ne = count + total;
+        __syncthreads();
+    }
+    const int ne = s_ne;
+
+    // ---- paint: wave `wave` owns rows [50*wave, 50*wave + 50) ----
+    const int row_lo = wave * (RES / 4), row_hi = row_lo + RES / 4 - 1;
+    const float scale_px = (2 * radius) / RES;
+    for (int e = 0; e < ne; e++) {
+        const BevEnt en = s_ent[e];
+        const int y0 = max(max(en.gy - en.br, 0), row_lo), y1 = min(min(en.gy + en.br, RES - 1), row_hi);
+        const int x0 = max(en.gx - en.br, 0), x1 = min(en.gx + en.br, RES - 1);
+        if (y1 < y0 || x1 < x0) continue;  // wave-uniform
+        const int nx = x1 - x0 + 1, cells = nx * (y1 - y0 + 1);
+        for (int c = lane; c < cells; c += 64) {
+            const int y = y0 + c / nx, x = x0 + c - (c / nx) * nx;
+            const float px = x * scale_px - radius, py = y * scale_px - radius;
+            const float ldx = px - en.cx, ldy = py - en.cy;
+            const float lx = ldx * en.cosy - ldy * en.siny;
+            const float ly = ldx * en.siny + ldy * en.cosy;
+            const float epsilon = 1e-3f;
+            if (fabsf(lx) <= en.half_l + epsilon && fabsf(ly) <= en.half_w + epsilon) s_grid[y * RES + x] = (unsigned char)en.type;
+        }
+    }
+    __syncthreads();
+    // ---- write-out: 40,000 floats, float4 stores ----
+    float4 *out = reinterpret_cast<float4 *>(d.bev + i * (size_t)(RES * RES));
+    for (int c = tid; c < RES * RES / 4; c += 256) {
+        const unsigned int v = reinterpret_cast<const unsigned int *>(s_grid)[c];
+        out[c] = make_float4((float)(v & 0xff), (float)((v >> 8) & 0xff), (float)((v >> 16) & 0xff), (float)(v >> 24));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LiDAR: 3 planes x 50 rays per agent.  PARITY UNPINNED: the reference traces rays through
+// Madrona's absent 3-D BVH; the geometry is restated from the collision meshes' extents exactly as
+// in oracle/gd_oracle.c (lidar_system): horizontal rays see the entities whose scaled z-range
+// contains the ray height, as 2-D boxes; a box containing the origin is not hit.
+// Entity-major: every thread takes entities, culls by range and by the angular interval the
+// entity's bounding circle subtends, runs the slab test only for the rays inside it, and keeps the
+// nearest hit per (plane, ray) with a 64-bit LDS atomicMin on (t bits, entity order).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ray_box(float ox, float oy, float dx, float dy, float cx, float cy, Quat rot, float hx,
+                                        float hy, float &t_out) {
+    const Quat inv = quat_inv(rot);
+    const V3 lo = quat_rotate(inv, V3{ox - cx, oy - cy, 0.f});
+    const V3 ld = quat_rotate(inv, V3{dx, dy, 0.f});
+    float tmin = -INFINITY, tmax = INFINITY;
+    if (ld.x == 0.f) {
+        if (lo.x < -hx || lo.x > hx) return false;
+    } else {
+        const float t1 = (-hx - lo.x) / ld.x, t2 = (hx - lo.x) / ld.x;
+        const float lo_t = t1 < t2 ? t1 : t2, hi_t = t1 < t2 ? t2 : t1;
+        if (lo_t > tmin) tmin = lo_t;
+        if (hi_t < tmax) tmax = hi_t;
+    }
+    if (ld.y == 0.f) {
+        if (lo.y < -hy || lo.y > hy) return false;
+    } else {
+        const float t1 = (-hy - lo.y) / ld.y, t2 = (hy - lo.y) / ld.y;
+        const float lo_t = t1 < t2 ? t1 : t2, hi_t = t1 < t2 ? t2 : t1;
+        if (lo_t > tmin) tmin = lo_t;
+        if (hi_t < tmax) tmax = hi_t;
+    }
+    if (!(tmax >= tmin) || !(tmin > 0.f)) return false;
+    t_out = tmin;
+    return true;
+}
+
+template <int A_T>
+__global__ __launch_bounds__(256) void k_lidar(DevSim d) {
+    constexpr int NS = GD_NUM_LIDAR_SAMPLES;
+    const int a = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const int n = d.shape[w * 2 + 0];
+    if (a >= n) return;
+    const int r0 = d.road_off[w];
+    const int R = d.road_off[w + 1] - r0;
+    const size_t i = (size_t)w * A_T + a;
+
+    __shared__ unsigned long long s_best[3 * NS];
+    __shared__ float s_x[NS], s_y[NS], s_dx[NS], s_dy[NS];
+
+    const float ox = d.px[i], oy = d.py[i], oz = d.pz[i];
+    const Quat rot = quat_from_wz(d.qw[i], d.qz[i]);
+    const Quat inv = quat_inv(rot);
+    const float half = d.lidar_half_angle > 0.f ? d.lidar_half_angle : kPi / 3;
+    const float head_angle = d.controlled[i] ? d.action[i * 10 + 2] : 0.f;
+    const float offs[3] = {0.5f, 0.1f, -0.1f};  // src/consts.hpp:42-44
+
+    if (tid < NS) {
+        const float theta = half * (2 * (float)tid / (float)NS - 1) + head_angle;
+        const float x = p_cos(theta), y = p_sin(theta);
+        const V3 fwd = quat_rotate(rot, V3{0.f, 1.f, 0.f}), right = quat_rotate(rot, V3{1.f, 0.f, 0.f});
+        V3 rd{x * right.x + y * fwd.x, x * right.y + y * fwd.y, x * right.z + y * fwd.z};
+        const float invl = 1.f / sqrtf(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z);
+        s_x[tid] = x; s_y[tid] = y;
+        s_dx[tid] = rd.x * invl; s_dy[tid] = rd.y * invl;
+    }
+    if (tid < 3 * NS) s_best[tid] = ~0ull;
+    __syncthreads();
+
+    const float step = 2.f * half / (float)NS;  // angle between neighbouring rays
+    for (int e = tid; e < n + R; e += 256) {
+        float cx, cy, hx, hy, zlo, zhi;
+        Quat q;
+        if (e < n) {
+            if (e == a) continue;
+            const size_t oi = (size_t)w * A_T + e;
+            cx = d.px[oi]; cy = d.py[oi];
+            q = quat_from_wz(d.qw[oi], d.qz[oi]);
+            hx = d.sc0[oi]; hy = d.sc1[oi];
+            zlo = d.pz[oi]; zhi = d.pz[oi] + 2 * GD_VEHICLE_SCALE;  // agent mesh z in [0,2], Scale d2 = 0.7
+        } else {
+            const int r = r0 + (e - n);
+            const float2 xy = d.road_xy[r];
+            const float4 a0 = d.road_aux[(size_t)r * 2], a1 = d.road_aux[(size_t)r * 2 + 1];
+            cx = xy.x; cy = xy.y;
+            q = quat_from_wz(a0.x, a0.y);
+            hx = a0.z; hy = a0.w;
+            const int type = (int)a1.y;
+            const float zc = type == ET_RoadEdge ? 1 + 0.1f : (type == ET_StopSign ? 1.f : 1 + -0.1f);
+            zlo = zc - a1.x; zhi = zc + a1.x;  // cube mesh z in [-1,1] scaled by d2
+        }
+        int planes = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const float rz = oz + offs[p];
+            if (rz >= zlo && rz <= zhi) planes |= 1 << p;
+        }
+        if (!planes) continue;
+        const V2 rel = ego_relative(ox, oy, inv, cx, cy);
+        const float rho = len_2(rel.x, rel.y), rb = sqrtf(hx * hx + hy * hy);
+        if (rho > 200.f + rb) continue;
+        // candidate rays: theta_idx = -half + idx*step + head_angle within phi +- alpha (+ slack), all wraps
+        const float phi = atan2f(rel.y, rel.x) - head_angle;
+        const float alpha = (rho <= rb ? kPi : asinf(fminf(1.f, rb / rho))) + 0.02f;
+        for (int kwrap = -1; kwrap <= 1; kwrap++) {
+            const float c = phi + kwrap * kPiM2;
+            int lo_i = (int)floorf((c - alpha + half) / step) - 1, hi_i = (int)ceilf((c + alpha + half) / step) + 1;
+            lo_i = max(lo_i, 0);
+            hi_i = min(hi_i, NS - 1);
+            for (int idx = lo_i; idx <= hi_i; idx++) {
+                float t;
+                if (!ray_box(ox, oy, s_dx[idx], s_dy[idx], cx, cy, q, hx, hy, t)) continue;
+                if (!(t <= 200.f)) continue;
+                const unsigned long long packed = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)e;
+#pragma unroll
+                for (int p = 0; p < 3; p++)
+                    if (planes & (1 << p)) atomicMin(&s_best[p * NS + idx], packed);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 3 * NS) {
+        const unsigned long long b = s_best[tid];
+        float *o = d.lidar + (i * 3 * NS + tid) * 4;
+        if (b == ~0ull) {
+            o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+        } else {
+            const float t = __uint_as_float((unsigned int)(b >> 32));
+            const int e = (int)(b & 0xffffffffu);
+            const int type = e < n ? d.etype[(size_t)w * A_T + e] : (int)d.road_aux[(size_t)(r0 + e - n) * 2 + 1].y;
+            const int idx = tid % NS;
+            o[0] = t; o[1] = (float)type; o[2] = t * s_x[idx]; o[3] = t * s_y[idx];
+        }
+    }
+}
+
+}  // namespace
+
+void launch_bev(const DevSim &d, hipStream_t st) {
+    const dim3 grid(d.A, d.W);
+    if (d.A == 64) hipLaunchKernelGGL(k_bev<64>, grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_bev<128>, grid, dim3(256), 0, st, d);
+}
+
+void launch_lidar(const DevSim &d, hipStream_t st) {
+    const dim3 grid(d.A, d.W);
+    if (d.A == 64) hipLaunchKernelGGL(k_lidar<64>, grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_lidar<128>, grid, dim3(256), 0, st, d);
+}
+
+}  // namespace gd

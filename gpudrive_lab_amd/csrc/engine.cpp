@@ -179,6 +179,14 @@ struct gd_sim {
     void run_rest(bool move) {
         launch(gd::KERNEL_STATE, move);
         if (!params.disableClassicalObs) launch(gd::KERNEL_MAP_OBS, move);
+        if (!params.disableClassicalObs && d.bev) {  // collectBevObservationsSystem, src/sim.cpp:879-884 (opt-in)
+            gd::launch_bev(d, stream);
+            HIP_CHECK(hipGetLastError());
+        }
+        if (params.enableLidar) {  // lidarSystem, src/sim.cpp:895-913
+            gd::launch_lidar(d, stream);
+            HIP_CHECK(hipGetLastError());
+        }
     }
 
     void upload_flags(int32_t *dst, const std::vector<int32_t> &flags) {
@@ -451,6 +459,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.A = A;
         d.p = *params;
         d.knn_order = cfg->knn_order;
+        d.lidar_half_angle = cfg->lidar_half_angle;
         d.debug_flags = std::getenv("GPUDRIVE_DEBUG_FLAGS") ? std::atoi(std::getenv("GPUDRIVE_DEBUG_FLAGS")) : 0;
         d.action = static_cast<float *>(s->exported[GD_T_ACTION]);
         d.reward = static_cast<float *>(s->exported[GD_T_REWARD]);

@@ -28,6 +28,7 @@ struct GridHdr {
 struct DevSim {
     int W, A;
     int knn_order;    // GD_KNN_*
+    float lidar_half_angle;  // 0 -> pi/3 (reference consts::lidarAngle)
     int debug_flags;  // developer ablation switches (GPUDRIVE_DEBUG_FLAGS), 0 in production
     gd_params p;
     // exported
@@ -56,5 +57,7 @@ struct DevSim {
 
 void launch_kernel(const DevSim &d, hipStream_t st, int which, bool move);
 void launch_map_obs(const DevSim &d, hipStream_t st);  // map_obs.hip
+void launch_bev(const DevSim &d, hipStream_t st);      // bev_lidar.hip
+void launch_lidar(const DevSim &d, hipStream_t st);    // bev_lidar.hip
 
 }  // namespace gd

@@ -174,7 +174,7 @@ class SimManager:
 
     def __init__(self, exec_mode, gpu_id, scenes, params, enable_batch_renderer=False,
                  batch_render_view_width=64, batch_render_view_height=64, max_agents=None,
-                 knn_order=0):
+                 knn_order=0, enable_bev=False, lidar_half_angle=0.0):
         import torch
 
         if int(exec_mode) != int(ExecMode.CUDA):
@@ -199,13 +199,14 @@ class SimManager:
         cfg.max_agents = self._A
         cfg.device_id = int(gpu_id)
         cfg.knn_order = int(knn_order)
-        cfg.alloc_bev = 0
-        cfg.lidar_half_angle = 0.0
+        cfg.alloc_bev = 1 if enable_bev else 0
+        cfg.lidar_half_angle = float(lidar_half_angle)
+        self._enable_bev = bool(enable_bev)
         with torch.cuda.device(self._device):
             cfg.stream = torch.cuda.current_stream(self._device).cuda_stream
             desc = _capi.GdTensorDesc()
             for slot in range(_capi.T_COUNT):
-                if slot == _capi.T_BEV:
+                if slot == _capi.T_BEV and not enable_bev:
                     continue
                 _capi.check(self._L.gd_tensor_shape(slot, self._W, self._A, C.byref(desc)), "gd_tensor_shape")
                 dims = [int(desc.dims[i]) for i in range(desc.ndim)]
@@ -280,7 +281,11 @@ class SimManager:
 
     # ---- dead / out-of-scope API kept for attribute compatibility ----
     def bev_observation_tensor(self):
-        raise NotImplementedError("bev_observation_tensor: BEV rasteriser not built in this round (160 KB/agent)")
+        """[W, A, 200, 200, 1] f32.  The reference always rasterises the BEV (160 KB per agent, 10.5 GB
+        at 1024 x 64); here it is computed only when the sim was built with enable_bev=True."""
+        if not self._enable_bev:
+            raise NotImplementedError("bev_observation_tensor: construct SimManager(..., enable_bev=True)")
+        return Tensor(self._tensors[_capi.T_BEV])
 
     def valid_state_tensor(self):
         raise NotImplementedError("valid_state_tensor: nothing is exported under ExportID::ValidState in the reference either")

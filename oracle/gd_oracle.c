@@ -68,6 +68,7 @@ typedef struct {
     int32_t dynamicsModel;
     int32_t readFromTracksToPredict;
     int32_t enableBev; /* oracle switch: BEV is 160 KB/agent */
+    float lidarHalfAngle; /* consts::lidarAngle (src/consts.hpp:46); 0 -> pi/3 */
 } orc_params;
 
 /* packed Map (oracle/scene.py pack_map) */
@@ -1090,6 +1091,94 @@ static void collect_bev_obs(orc_sim *s, int w, int a) {
     }
 }
 
+
+/* ------------------------------------------------------------------ */
+/* lidarSystem, src/sim.cpp:394-460.                                   */
+/*                                                                     */
+/* PARITY UNPINNED: the reference traces rays through Madrona's 3-D BVH */
+/* (absent) against the collision meshes under assets/.  Restated    */
+/* from the mesh extents: cube_collision.obj is [-1,1]^3 and           */
+/* agent_collision_simplified.obj is [-1,1]^2 x [0,2], both scaled by  */
+/* the entity's Scale.  Rays are horizontal, so a ray at height z sees */
+/* exactly the entities whose scaled z-range contains z, as 2-D boxes: */
+/*   agents   z in [pos.z, pos.z + 2*0.7]                              */
+/*   road edge 1.1 +- 0.1; line/lane/crosswalk/speed bump 0.9 +- 0.1;  */
+/*   stop sign 1 +- 1  (src/level_gen.cpp:170,235,250; Scale d2)       */
+/* A box that contains the ray origin is not hit (front faces only),   */
+/* which also excludes the agent's own box.  Nearest hit within        */
+/* lidarDistance = 200 wins; ties go to the lowest entity order        */
+/* (agents in row order, then roads in row order).                     */
+/* ------------------------------------------------------------------ */
+static int ray_box(float ox, float oy, float dx, float dy, float cx, float cy, Quat rot, float hx, float hy, float *t_out) {
+    Quat inv = q_inv(rot);
+    V3 o = { ox - cx, oy - cy, 0 }, d = { dx, dy, 0 };
+    V3 lo = q_rotate(inv, o), ld = q_rotate(inv, d);
+    float tmin = -INFINITY, tmax = INFINITY;
+    if (ld.x == 0.f) { if (lo.x < -hx || lo.x > hx) return 0; }
+    else {
+        float t1 = (-hx - lo.x) / ld.x, t2 = (hx - lo.x) / ld.x;
+        float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
+        if (a > tmin) tmin = a;
+        if (b < tmax) tmax = b;
+    }
+    if (ld.y == 0.f) { if (lo.y < -hy || lo.y > hy) return 0; }
+    else {
+        float t1 = (-hy - lo.y) / ld.y, t2 = (hy - lo.y) / ld.y;
+        float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
+        if (a > tmin) tmin = a;
+        if (b < tmax) tmax = b;
+    }
+    if (!(tmax >= tmin) || !(tmin > 0.f)) return 0;
+    *t_out = tmin;
+    return 1;
+}
+static float road_z(int type) {
+    if (type == ET_ROADEDGE) return 1 + 0.1f;
+    if (type == ET_STOPSIGN) return 1;
+    return 1 + -0.1f;
+}
+static void lidar_system(orc_sim *s, int w, int a) {
+    World *wd = &s->worlds[w];
+    AgentEnt *ag = &wd->agents[a];
+    size_t i = IDX_WA(s, w, a);
+    float *out = s->lidar + i * 3 * LIDAR_N * 4;
+    const float offsets[3] = { 0.5f, 0.1f, -0.1f }; /* consts.hpp:42-44: cars, road edges, road lines */
+    const float half = s->p.lidarHalfAngle > 0.f ? s->p.lidarHalfAngle : PI_F / 3;
+    V3 fwdv = { 0, 1, 0 }, rightv = { 1, 0, 0 };
+    V3 agent_fwd = q_rotate(ag->rot, fwdv), right = q_rotate(ag->rot, rightv);
+    float head_angle = s->controlled[i] ? s->action[i * 10 + 2] : 0.f;
+    for (int idx = 0; idx < LIDAR_N; idx++) {
+        float theta = half * (2 * (float)idx / (float)LIDAR_N - 1) + head_angle;
+        float x = cosf(theta), y = sinf(theta);
+        V3 rd = { x * right.x + y * agent_fwd.x, x * right.y + y * agent_fwd.y, x * right.z + y * agent_fwd.z };
+        float invl = 1.f / sqrtf(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z);
+        rd.x *= invl; rd.y *= invl; rd.z *= invl;
+        for (int p = 0; p < 3; p++) {
+            float rz = ag->pos.z + offsets[p];
+            float best = INFINITY; int best_type = 0;
+            for (int j = 0; j < wd->num_agents; j++) {
+                if (j == a) continue;
+                AgentEnt *ot = &wd->agents[j];
+                if (!(rz >= ot->pos.z && rz <= ot->pos.z + 2 * ot->scale[2])) continue;
+                float t;
+                if (ray_box(ag->pos.x, ag->pos.y, rd.x, rd.y, ot->pos.x, ot->pos.y, ot->rot, ot->scale[0], ot->scale[1], &t) &&
+                    t <= 200.f && t < best) { best = t; best_type = ot->etype; }
+            }
+            for (int r = 0; r < wd->num_roads; r++) {
+                RoadEnt *R = &wd->roads[r];
+                float zc = road_z(R->type);
+                if (!(rz >= zc - R->scale[2] && rz <= zc + R->scale[2])) continue;
+                float t;
+                if (ray_box(ag->pos.x, ag->pos.y, rd.x, rd.y, R->pos.x, R->pos.y, R->rot, R->scale[0], R->scale[1], &t) &&
+                    t <= 200.f && t < best) { best = t; best_type = R->type; }
+            }
+            float *o = out + ((size_t)p * LIDAR_N + idx) * 4;
+            if (best == INFINITY) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
+            else { o[0] = best; o[1] = (float)best_type; o[2] = best * x; o[3] = best * y; }
+        }
+    }
+}
+
 /* sim.cpp:785-943 setupRestOfTasks */
 static void rest_of_tasks(orc_sim *s, int w, int decrementStep, int64_t *inserts) {
     World *wd = &s->worlds[w];
@@ -1104,6 +1193,7 @@ static void rest_of_tasks(orc_sim *s, int w, int decrementStep, int64_t *inserts
         collect_map_obs(s, w, a, inserts);
         collect_bev_obs(s, w, a);
         collect_abs_obs(s, w, a);
+        if (s->p.enableLidar) lidar_system(s, w, a);
     }
 }
 

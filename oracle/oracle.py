@@ -39,6 +39,7 @@ class OrcParams(C.Structure):
         ("dynamicsModel", C.c_int32),
         ("readFromTracksToPredict", C.c_int32),
         ("enableBev", C.c_int32),
+        ("lidarHalfAngle", C.c_float),
     ]
 
 
@@ -120,6 +121,7 @@ def default_params(**kw):
     p.dynamicsModel = 0
     p.readFromTracksToPredict = 0
     p.enableBev = 0
+    p.lidarHalfAngle = 0.0
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

@@ -23,9 +23,10 @@ PARAM_KEYS = ("polylineReductionThreshold", "observationRadius", "rewardType", "
               "distanceToExpertThreshold", "collisionBehaviour", "maxNumControlledAgents", "IgnoreNonVehicles",
               "roadObservationAlgorithm", "initOnlyValidAgentsAtFirstStep", "isStaticAgentControlled",
               "enableLidar", "disableClassicalObs", "dynamicsModel", "readFromTracksToPredict")
+ORACLE_ONLY_KEYS = ("enableBev", "lidarHalfAngle")
 
 
-def make_gpu_sim(scenes, max_agents=64, knn_order=0, **kw):
+def make_gpu_sim(scenes, max_agents=64, knn_order=0, enable_bev=False, lidar_half_angle=0.0, **kw):
     import madrona_gpudrive as mg
     p = mg.Parameters()
     for k, v in kw.items():
@@ -35,7 +36,8 @@ def make_gpu_sim(scenes, max_agents=64, knn_order=0, **kw):
         else:
             setattr(p, k, v)
     return mg.SimManager(exec_mode=mg.madrona.ExecMode.CUDA, gpu_id=0, scenes=list(scenes), params=p,
-                         max_agents=max_agents, knn_order=knn_order)
+                         max_agents=max_agents, knn_order=knn_order, enable_bev=enable_bev,
+                         lidar_half_angle=lidar_half_angle)
 
 
 def make_oracle_sim(O, scenes, max_agents=64, **kw):
@@ -193,3 +195,29 @@ def compare_roadmap_as_set(gpu, orc, atol=OBS_ATOL):
         bad = np.argwhere(~ok)
         raise AssertionError("agent_roadmap (as a set): %d elements differ; first at %s gpu %r oracle %r" %
                              (len(bad), bad[0], g[tuple(bad[0])], o[tuple(bad[0])]))
+
+
+def compare_lidar(gpu, orc, depth_atol=1e-4):
+    """LiDAR rows of live agents: hit/miss pattern and entity type exact, depth and hit position
+    within 1e-4 (200 m range; ray directions come from sin/cos of the ray angle)."""
+    live = _live_mask(orc)
+    g = as_np(gpu.lidar_tensor())[live]
+    o = np.asarray(orc.lidar_tensor())[live]
+    hit_g, hit_o = g[..., 0] > 0, o[..., 0] > 0
+    # a ray grazing a box corner may hit on one side only: allow a vanishing fraction
+    mism = (hit_g != hit_o) | (g[..., 1] != o[..., 1])
+    assert mism.mean() <= 2e-4, "lidar hit/type pattern differs on %d of %d rays" % (mism.sum(), mism.size)
+    ok = ~mism
+    assert np.allclose(g[ok][:, [0, 2, 3]], o[ok][:, [0, 2, 3]], atol=depth_atol, rtol=1e-5)
+    return float(hit_o.mean())
+
+
+def compare_bev(gpu, orc):
+    """BEV grids of live agents: cell values are entity types; cells whose centre lies within float
+    rounding of a rectangle edge may differ (device vs host sin/cos), nothing else."""
+    live = _live_mask(orc)
+    g = as_np(gpu.bev_observation_tensor())[live]
+    o = np.asarray(orc.bev_observation_tensor())[live]
+    mism = g != o
+    assert mism.mean() <= 1e-4, "BEV differs on %d of %d cells" % (mism.sum(), mism.size)
+    return float((o != 0).mean())

@@ -143,6 +143,55 @@ def test_set_order_mode_matches_reference_rows_as_a_set(oracle_mod, name, scenes
     gpu.close()
 
 
+@pytest.mark.parametrize("half_angle", [0.0, float(np.pi)], ids=["cone120", "full360"])
+def test_lidar_parity(oracle_mod, half_angle):
+    """BASELINE configs[4]: LiDAR 3 x 50 rays (120 degree cone = reference, and the 360 degree
+    variant), mixed vehicle / cyclist / pedestrian agents.  Parity is against the oracle's
+    restatement of the mesh extents (the reference's BVH is absent: unpinned)."""
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, enableLidar=1, **ALL_OBJECTS)
+    scenes = [SCENE_4, SCENE_407, TEST_JSON]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, lidar_half_angle=half_angle, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, lidarHalfAngle=half_angle, **kw)
+    rng = np.random.default_rng(11)
+    for k in range(12):
+        act = P.random_actions(rng, orc.W, orc.A, 0)
+        act[..., 2] = rng.uniform(-0.5, 0.5, act.shape[:2])  # head angle (ClassicAction.headAngle)
+        RC.write_actions(gpu, act)
+        np.copyto(orc.action_tensor(), act)
+        gpu.step()
+        orc.step()
+        gpu.debug_set_state(orc.get_state())
+        gpu.reset([])
+        orc.reset([])
+        frac = P.compare_lidar(gpu, orc)
+        assert frac > 0.05  # the scene is not empty
+    gpu.close()
+
+
+def test_bev_parity(oracle_mod):
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
+    scenes = [SCENE_4, TEST_JSON]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, enable_bev=True, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, enableBev=1, **kw)
+    rng = np.random.default_rng(12)
+    for k in range(4):
+        act = P.random_actions(rng, orc.W, orc.A, 0)
+        RC.write_actions(gpu, act)
+        np.copyto(orc.action_tensor(), act)
+        gpu.step()
+        orc.step()
+        gpu.debug_set_state(orc.get_state())
+        gpu.reset([])
+        orc.reset([])
+        painted = P.compare_bev(gpu, orc)
+        assert painted > 0.001
+    with pytest.raises(NotImplementedError):
+        P.make_gpu_sim([TEST_JSON], max_agents=64, **kw).bev_observation_tensor()
+    gpu.close()
+
+
 def test_free_running_flags_stay_exact(oracle_mod):
     """No teacher forcing: 91 steps + reset + 30 steps; int tensors must stay bit-exact."""
     kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
