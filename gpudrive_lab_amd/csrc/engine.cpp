@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -460,6 +461,14 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.p = *params;
         d.knn_order = cfg->knn_order;
         d.lidar_half_angle = cfg->lidar_half_angle;
+        {
+            // radiusFilter keeps length() <= radius (src/knn.hpp:88); on squared keys: key <= kmax
+            const float r = params->observationRadius;
+            float k = r * r;
+            while (k > 0.f && sqrtf(k) > r) k = std::nextafterf(k, 0.f);
+            while (sqrtf(std::nextafterf(k, INFINITY)) <= r) k = std::nextafterf(k, INFINITY);
+            d.radius_key_max = r >= 0.f ? k : -1.f;
+        }
         d.debug_flags = std::getenv("GPUDRIVE_DEBUG_FLAGS") ? std::atoi(std::getenv("GPUDRIVE_DEBUG_FLAGS")) : 0;
         d.action = static_cast<float *>(s->exported[GD_T_ACTION]);
         d.reward = static_cast<float *>(s->exported[GD_T_REWARD]);

@@ -29,6 +29,7 @@ struct DevSim {
     int W, A;
     int knn_order;    // GD_KNN_*
     float lidar_half_angle;  // 0 -> pi/3 (reference consts::lidarAngle)
+    float radius_key_max;    // largest fp32 k with sqrtf(k) <= observationRadius (radiusFilter on squared keys)
     int debug_flags;  // developer ablation switches (GPUDRIVE_DEBUG_FLAGS), 0 in production
     gd_params p;
     // exported

@@ -96,13 +96,97 @@ struct HeapCol {
         const int last = min((2 << depth) - 2, (len - 2) / 2);
         for (int parent = first + sub; parent <= last; parent += g) adjust(parent, len, key(parent), index(parent));
     }
-    // pop_heap + replace last + push_heap, src/knn.hpp:138-151
-    __device__ __forceinline__ void replace_top(float xk, unsigned short xi) const {
+    // pop_heap + replace last + push_heap (src/knn.hpp:138-151) as straight-line code.
+    //
+    // pop_heap moves the root to slot K-1 (overwritten by the new element right after, so that store
+    // is dropped), sifts the hole down from the root of the 199-element heap (always 6 levels, since
+    // second = 2h+2 <= 126 < 199, and a 7th iff the level-6 node has children, h <= 98; `second == len`
+    // cannot happen: second is even, len is odd), then pushes the old last element x up from the leaf
+    // hole.  The values x meets on its way up are exactly the children just moved, which are still in
+    // registers, so its final level needs no LDS read.  push_heap then lifts the new element y from
+    // slot K-1 along the fixed ancestor chain 99,49,24,11,5,2,0; those seven slots are prefetched with
+    // the first level and patched where the pop rewrote them.  One LDS round trip per sift-down level
+    // is the only dependent chain left; there are no data-dependent loops.
+    __device__ __forceinline__ void replace_top(float yk, unsigned short yi) const {
+        constexpr int Q[7] = {0, 2, 5, 11, 24, 49, 99};
         const float lk = key(K - 1);
         const unsigned short li = index(K - 1);
-        move(K - 1, 0);
-        adjust(0, K - 1, lk, li);
-        push(K - 1, 0, xk, xi);
+        float qk[7];
+        unsigned short qi[7];
+#pragma unroll
+        for (int l = 1; l < 7; l++) { qk[l] = key(Q[l]); qi[l] = index(Q[l]); }
+        int ph[8];
+        float ck[7];
+        unsigned short ci[7];
+        ph[0] = 0;
+#pragma unroll
+        for (int l = 0; l < 6; l++) {
+            const int second = 2 * ph[l] + 2;
+            const float kr = key(second), kl = key(second - 1);
+            const unsigned short ir = index(second), il = index(second - 1);
+            const bool left = kr < kl;
+            ck[l] = left ? kl : kr;
+            ci[l] = left ? il : ir;
+            ph[l + 1] = second - (left ? 1 : 0);
+        }
+        const int second6 = 2 * ph[6] + 2;
+        const bool has7 = second6 < K - 1;
+        ck[6] = 0.f; ci[6] = 0; ph[7] = 0;
+        if (has7) {
+            const float kr = key(second6), kl = key(second6 - 1);
+            const unsigned short ir = index(second6), il = index(second6 - 1);
+            const bool left = kr < kl;
+            ck[6] = left ? kl : kr;
+            ci[6] = left ? il : ir;
+            ph[7] = second6 - (left ? 1 : 0);
+        }
+        const int m = has7 ? 7 : 6;
+        // level j at which x comes to rest: it climbs past level l+1 while the value now at level l is smaller
+        int j = m;
+        bool climbing = true;
+#pragma unroll
+        for (int l = 6; l >= 0; l--) {
+            if (l < m) {
+                climbing = climbing && (ck[l] < lk);
+                if (climbing) j = l;
+            }
+        }
+        // new contents of the path slots ph[0..m]
+        float nk[8];
+        unsigned short ni[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            const float below_k = l > 0 ? ck[l - 1] : 0.f;
+            const unsigned short below_i = l > 0 ? ci[l - 1] : (unsigned short)0;
+            const float here_k = l < 7 ? ck[l] : 0.f;
+            const unsigned short here_i = l < 7 ? ci[l] : (unsigned short)0;
+            nk[l] = l < j ? here_k : (l == j ? lk : below_k);
+            ni[l] = l < j ? here_i : (l == j ? li : below_i);
+            if (l <= m) set(ph[l], nk[l], ni[l]);
+        }
+        // current values of the ancestor chain of slot K-1 (patched where the pop rewrote a slot)
+        float cur_k[7];
+        unsigned short cur_i[7];
+#pragma unroll
+        for (int l = 0; l < 7; l++) {
+            const bool rewritten = ph[l] == Q[l];  // ph[l] lives on level l, like Q[l]; l <= 6 <= m
+            cur_k[l] = rewritten ? nk[l] : qk[l];
+            cur_i[l] = rewritten ? ni[l] : qi[l];
+        }
+        // y rests at chain position t (7 = slot K-1, l = slot Q[l]); everything below t shifts down one
+        int t = 7;
+        bool up = true;
+#pragma unroll
+        for (int l = 6; l >= 0; l--) {
+            up = up && (cur_k[l] < yk);
+            if (up) t = l;
+        }
+#pragma unroll
+        for (int u = 7; u >= 0; u--) {
+            const int slot = u == 7 ? K - 1 : Q[u];
+            if (u > t) set(slot, cur_k[u - 1], cur_i[u - 1]);
+            else if (u == t) set(slot, yk, yi);
+        }
     }
     // radiusFilter, src/knn.hpp:83-97 (swap-remove in heap-array order); returns newBeyond
     __device__ __forceinline__ int radius_filter(int len, float radius) const {
@@ -189,15 +273,15 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
             inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
         }
         float2 *tile = s_tile[wave];
-        // bits of this agent's G lanes inside a ballot -> G contiguous bits (road order)
-        auto agent_bits = [&](bool pass) -> unsigned int {
-            const unsigned long long m = __ballot(pass) >> al;
-            unsigned int bits = 0;
+        // A lane owns PL = 32/G consecutive roads of every 32-road chunk (t = sub*PL + k); its PL pass
+        // bits sit at bit sub*PL of the chunk word, and the G lanes of an agent OR their parts together
+        // with log2(G) cross-lane steps: no per-road ballot.
+        constexpr int PL = C / G;
+        auto agent_or = [&](unsigned int part) -> unsigned int {
 #pragma unroll
-            for (int g = 0; g < G; g++) bits |= (unsigned int)((m >> (g * APW)) & 1ull) << g;
-            return bits;
+            for (int st = APW; st < 64; st <<= 1) part |= (unsigned int)__shfl_xor((int)part, st);
+            return part;
         };
-        const unsigned int below = (1u << sub) - 1u;
 
         for (int win = 0; win < R; win += WW * C) {
             const int win_end = min(R, win + WW * C);
@@ -208,52 +292,64 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                 wave_sync();
                 if (lane < tn) tile[lane] = d.road_xy[(size_t)r0 + base + lane];
                 wave_sync();
-                unsigned int word = 0;
                 if (knn) {
                     // roads with index < K go straight into the array (src/knn.hpp:112-120)
                     const int direct_end = min(tn, max(0, K - base));
-                    for (int t = sub; t < direct_end; t += G) {
+                    if (direct_end > 0) {
                         if (live) {
-                            const float2 xy = tile[t];
-                            const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                            heap.set(base + t, len2_2(rel.x, rel.y), (unsigned short)(base + t));
+#pragma unroll
+                            for (int k = 0; k < PL; k++) {
+                                const int t = sub * PL + k;
+                                if (t < direct_end) {
+                                    const float2 xy = tile[t];
+                                    const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                                    heap.set(base + t, len2_2(rel.x, rel.y), (unsigned short)(base + t));
+                                }
+                            }
                         }
-                    }
-                    if (direct_end > 0 && base + direct_end == K) {
-                        for (int depth = 6; depth >= 0; depth--) {  // parents 0..99 live on levels 0..6
+                        if (base + direct_end == K) {
+                            for (int depth = 6; depth >= 0; depth--) {  // parents 0..99 live on levels 0..6
+                                wave_sync();
+                                if (live) heap.make_level(K, depth, sub, G);
+                            }
                             wave_sync();
-                            if (live) heap.make_level(K, depth, sub, G);
+                            thr = live ? heap.key(0) : -1.f;
                         }
-                        wave_sync();
-                        thr = live ? heap.key(0) : -1.f;
                     }
                     // conservative candidates: closer than the K-th distance at the window start
-                    for (int t0 = direct_end; t0 < tn; t0 += G) {
-                        const int t = t0 + sub;
-                        bool pass = false;
-                        if (live && t < tn) {
+                    unsigned int part = 0;
+                    if (direct_end < tn) {
+#pragma unroll
+                        for (int k = 0; k < PL; k++) {
+                            const int t = sub * PL + k;
                             const float2 xy = tile[t];
                             const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                            pass = len2_2(rel.x, rel.y) < thr;
+                            const bool pass = t >= direct_end && t < tn && len2_2(rel.x, rel.y) < thr;
+                            part |= (pass ? 1u : 0u) << t;
                         }
-                        word |= agent_bits(pass) << t0;
                     }
+                    const unsigned int word = agent_or(part);
                     if (sub == 0) s_mask[c * A_T + a] = word;
                 } else {
                     // AllEntitiesWithRadiusFiltering: first K in index order within the radius, sim.cpp:261-279
-                    for (int t0 = 0; t0 < tn; t0 += G) {
-                        const int t = t0 + sub;
-                        bool pass = false;
-                        if (live && t < tn) {
-                            const float2 xy = tile[t];
-                            const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                            pass = !(len_2(rel.x, rel.y) > radius);
-                        }
-                        const unsigned int bits = agent_bits(pass);
-                        const int pos = count + __popc(bits & below);
-                        if (pass && pos < K) s_idx[pos * A_T + a] = (unsigned short)(base + t);
-                        count += __popc(bits);
+                    unsigned int part = 0;
+#pragma unroll
+                    for (int k = 0; k < PL; k++) {
+                        const int t = sub * PL + k;
+                        const float2 xy = tile[t];
+                        const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                        const bool pass = live && t < tn && !(len_2(rel.x, rel.y) > radius);
+                        part |= (pass ? 1u : 0u) << t;
                     }
+                    const unsigned int word = agent_or(part);
+                    unsigned int mine = part;
+                    while (mine) {
+                        const int t = __ffs(mine) - 1;
+                        mine &= mine - 1;
+                        const int pos = count + __popc(word & ((1u << t) - 1u));
+                        if (pos < K) s_idx[pos * A_T + a] = (unsigned short)(base + t);
+                    }
+                    count += __popc(word);
                 }
             }
             // ---- DRAIN: one lane per agent replays its candidates of this window in road order ----
@@ -263,16 +359,31 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                     const int nwords = (win_end - win + C - 1) / C;
                     int c = 0;
                     unsigned int word = s_mask[a];
-                    for (;;) {
+                    // cursor over the candidate bits; the next candidate's (x, y) is fetched from L2
+                    // while the current one is replayed
+                    auto next = [&](int &r) -> bool {
                         while (word == 0 && ++c < nwords) word = s_mask[c * A_T + a];
-                        if (word == 0) break;
+                        if (word == 0) return false;
                         const int b = __ffs(word) - 1;
                         word &= word - 1;
-                        const int r = win + c * C + b;
-                        const float2 xy = d.road_xy[(size_t)r0 + r];
-                        const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
+                        r = win + c * C + b;
+                        return true;
+                    };
+                    const float2 *rxy = d.road_xy + r0;
+                    int r_cur = 0, r_nxt = 0;
+                    bool has = next(r_cur);
+                    float2 xy_cur = make_float2(0.f, 0.f);
+                    if (has) xy_cur = rxy[r_cur];
+                    while (has) {
+                        const bool has_n = next(r_nxt);
+                        float2 xy_nxt = xy_cur;
+                        if (has_n) xy_nxt = rxy[r_nxt];
+                        const V2 rel = ego_relative(ex, ey, inv, xy_cur.x, xy_cur.y);
                         const float key = len2_2(rel.x, rel.y);
-                        if (key < heap.key(0)) heap.replace_top(key, (unsigned short)r);
+                        if (key < heap.key(0)) heap.replace_top(key, (unsigned short)r_cur);
+                        r_cur = r_nxt;
+                        xy_cur = xy_nxt;
+                        has = has_n;
                     }
                 }
             }
