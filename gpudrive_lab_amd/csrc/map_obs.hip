@@ -107,7 +107,8 @@ struct HeapCol {
     // slot K-1 along the fixed ancestor chain 99,49,24,11,5,2,0; those seven slots are prefetched with
     // the first level and patched where the pop rewrote them.  One LDS round trip per sift-down level
     // is the only dependent chain left; there are no data-dependent loops.
-    __device__ __forceinline__ void replace_top(float yk, unsigned short yi) const {
+    // Returns the key of the new root.
+    __device__ __forceinline__ float replace_top(float yk, unsigned short yi) const {
         constexpr int Q[7] = {0, 2, 5, 11, 24, 49, 99};
         const float lk = key(K - 1);
         const unsigned short li = index(K - 1);
@@ -119,27 +120,35 @@ struct HeapCol {
         float ck[7];
         unsigned short ci[7];
         ph[0] = 0;
+        // Decisions use keys only, two levels per LDS round trip: the hole's two children AND its four
+        // grandchildren are fetched together, so the 6 unconditional levels cost 3 dependent round
+        // trips; the indices of the chosen children are fetched afterwards in one batch.
 #pragma unroll
-        for (int l = 0; l < 6; l++) {
-            const int second = 2 * ph[l] + 2;
-            const float kr = key(second), kl = key(second - 1);
-            const unsigned short ir = index(second), il = index(second - 1);
-            const bool left = kr < kl;
+        for (int l = 0; l < 6; l += 2) {
+            const int c2 = 2 * ph[l] + 2;                    // children c2-1, c2
+            const float kr = key(c2), kl = key(c2 - 1);
+            const float g0 = key(2 * c2 - 1), g1 = key(2 * c2), g2 = key(2 * c2 + 1), g3 = key(2 * c2 + 2);
+            const bool left = kr < kl;                       // children of (c2-1): 2c2-1, 2c2; of c2: 2c2+1, 2c2+2
             ck[l] = left ? kl : kr;
-            ci[l] = left ? il : ir;
-            ph[l + 1] = second - (left ? 1 : 0);
+            ph[l + 1] = c2 - (left ? 1 : 0);
+            const float hr = left ? g1 : g3, hl = left ? g0 : g2;
+            const int d2 = 2 * ph[l + 1] + 2;
+            const bool left2 = hr < hl;
+            ck[l + 1] = left2 ? hl : hr;
+            ph[l + 2] = d2 - (left2 ? 1 : 0);
         }
         const int second6 = 2 * ph[6] + 2;
         const bool has7 = second6 < K - 1;
         ck[6] = 0.f; ci[6] = 0; ph[7] = 0;
         if (has7) {
             const float kr = key(second6), kl = key(second6 - 1);
-            const unsigned short ir = index(second6), il = index(second6 - 1);
             const bool left = kr < kl;
             ck[6] = left ? kl : kr;
-            ci[6] = left ? il : ir;
             ph[7] = second6 - (left ? 1 : 0);
+            ci[6] = index(ph[7]);
         }
+#pragma unroll
+        for (int l = 0; l < 6; l++) ci[l] = index(ph[l + 1]);
         const int m = has7 ? 7 : 6;
         // level j at which x comes to rest: it climbs past level l+1 while the value now at level l is smaller
         int j = m;
@@ -187,6 +196,7 @@ struct HeapCol {
             if (u > t) set(slot, cur_k[u - 1], cur_i[u - 1]);
             else if (u == t) set(slot, yk, yi);
         }
+        return t == 0 ? yk : nk[0];
     }
     // radiusFilter, src/knn.hpp:83-97 (swap-remove in heap-array order); returns newBeyond
     __device__ __forceinline__ int radius_filter(int len, float radius) const {
@@ -374,13 +384,14 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                     bool has = next(r_cur);
                     float2 xy_cur = make_float2(0.f, 0.f);
                     if (has) xy_cur = rxy[r_cur];
+                    float top = heap.key(0);  // register copy of the K-th distance
                     while (has) {
                         const bool has_n = next(r_nxt);
                         float2 xy_nxt = xy_cur;
                         if (has_n) xy_nxt = rxy[r_nxt];
                         const V2 rel = ego_relative(ex, ey, inv, xy_cur.x, xy_cur.y);
                         const float key = len2_2(rel.x, rel.y);
-                        if (key < heap.key(0)) heap.replace_top(key, (unsigned short)r_cur);
+                        if (key < top) top = heap.replace_top(key, (unsigned short)r_cur);
                         r_cur = r_nxt;
                         xy_cur = xy_nxt;
                         has = has_n;
