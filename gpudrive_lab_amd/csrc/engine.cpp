@@ -589,6 +589,17 @@ int gd_tensor(gd_sim *s, int32_t id, gd_tensor_desc *out) {
     return GD_OK;
 }
 
+int gd_pack_observations(gd_sim *s, float *out, int64_t out_bytes) {
+    if (!s || !out) return fail(GD_ERR_INVALID, "gd_pack_observations: null argument");
+    const int64_t D = 6 + static_cast<int64_t>(s->A - 1) * 6 + GD_MAP_OBS_K * 13;
+    if (out_bytes < static_cast<int64_t>(s->W) * s->A * D * 4)
+        return fail(GD_ERR_INVALID, "gd_pack_observations: output buffer too small");
+    return guarded([&]() {
+        gd::launch_pack_obs(s->d, s->stream, out);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 int gd_sync(gd_sim *s) {
     if (!s) return fail(GD_ERR_INVALID, "gd_sync: null sim");
     return guarded([&]() { HIP_CHECK(hipStreamSynchronize(s->stream)); });

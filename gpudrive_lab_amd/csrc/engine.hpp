@@ -60,5 +60,6 @@ void launch_kernel(const DevSim &d, hipStream_t st, int which, bool move);
 void launch_map_obs(const DevSim &d, hipStream_t st);  // map_obs.hip
 void launch_bev(const DevSim &d, hipStream_t st);      // bev_lidar.hip
 void launch_lidar(const DevSim &d, hipStream_t st);    // bev_lidar.hip
+void launch_pack_obs(const DevSim &d, hipStream_t st, float *out);  // pack_obs.hip
 
 }  // namespace gd

@@ -279,6 +279,21 @@ class SimManager:
     def sync(self):
         _capi.check(self._L.gd_sync(self._h), "gd_sync")
 
+    def packed_observations(self, out=None):
+        """Extension (not in the reference module): the flattened, normalised observation that
+        `GPUDriveTorchEnv.get_obs()` assembles from the raw tensors (ego 6 | partners (A-1)*6 |
+        road points 200*13), written by one fused kernel.  Returns a [W, A, D] float32 tensor."""
+        import torch
+        D = 6 + (self._A - 1) * 6 + kMaxAgentMapObservationsCount * 13
+        if out is None:
+            out = getattr(self, "_packed", None)
+            if out is None:
+                out = self._packed = torch.empty((self._W, self._A, D), dtype=torch.float32, device=self._device)
+        assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == self._W * self._A * D
+        self._bind_stream()
+        _capi.check(self._L.gd_pack_observations(self._h, out.data_ptr(), out.numel() * 4), "gd_pack_observations")
+        return out
+
     # ---- dead / out-of-scope API kept for attribute compatibility ----
     def bev_observation_tensor(self):
         """[W, A, 200, 200, 1] f32.  The reference always rasterises the BEV (160 KB per agent, 10.5 GB

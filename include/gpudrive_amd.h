@@ -150,6 +150,11 @@ int gd_delete_agents(gd_sim *sim, const int32_t *worlds, const int32_t *offsets,
                      int32_t n_worlds);
 /* Manager::*Tensor() (src/mgr.cpp:656-902). */
 int gd_tensor(gd_sim *sim, int32_t id, gd_tensor_desc *out);
+/* Fused observation pack: writes what GPUDriveTorchEnv.get_obs() concatenates with
+ * norm_obs=True (gpudrive/env/env_torch.py:756-896,1172-1216) for every agent slot:
+ * out[W][A][6 + (A-1)*6 + 200*13] f32 = ego | partners | road points (type one-hot over 7).
+ * `out` is a device pointer of at least out_bytes bytes. */
+int gd_pack_observations(gd_sim *sim, float *out, int64_t out_bytes);
 /* Block until everything launched so far has finished (the reference's step() is synchronous). */
 int gd_sync(gd_sim *sim);
 /* Change the launch stream (e.g. torch's current stream). */

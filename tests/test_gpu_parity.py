@@ -192,6 +192,43 @@ def test_bev_parity(oracle_mod):
     gpu.close()
 
 
+def test_packed_observations_match_reference_python_golden():
+    """the fused pack kernel against golden vectors produced by the reference's own
+    gpudrive/datatypes code (tests/golden/make_obs_pack_golden.py, run in the authoring container)."""
+    import os
+    import torch
+    from tests.conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "obs_pack_golden.npz"))
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
+    gpu = P.make_gpu_sim([SCENE_4], max_agents=64, **kw)
+    n = g["self_obs"].shape[0]
+    dev = gpu.self_observation_tensor().to_torch().device
+    # the exported tensors are the live storage: overwrite the first n agent rows with the golden inputs
+    gpu.self_observation_tensor().to_torch()[0, :n] = torch.from_numpy(g["self_obs"]).to(dev)
+    gpu.partner_observations_tensor().to_torch()[0, :n] = torch.from_numpy(g["partner"]).to(dev)
+    gpu.agent_roadmap_tensor().to_torch()[0, :n] = torch.from_numpy(g["roadmap"]).to(dev)
+    out = gpu.packed_observations()
+    assert out.shape == (1, 64, 6 + 63 * 6 + 200 * 13)
+    got = out[0, :n].cpu().numpy()
+    # torch CPU divides, the kernel divides: bit-exact expected; allow one ulp of a [-1,1] value
+    assert np.allclose(got, g["expected"], atol=1.2e-7, rtol=0), np.abs(got - g["expected"]).max()
+    # and against a torch restatement on the device for every agent slot (incl. padding rows)
+    so = gpu.self_observation_tensor().to_torch()
+    po = gpu.partner_observations_tensor().to_torch()
+    ro = gpu.agent_roadmap_tensor().to_torch()
+    nm = lambda x: 2 * ((x + 1000) / 2000) - 1
+    ego = torch.stack([so[..., 0] / 100, so[..., 1] * 0.7 / 30, so[..., 2] * 0.7 / 15, nm(so[..., 4]), nm(so[..., 5]),
+                       so[..., 6]], -1)
+    part = torch.stack([po[..., 0] / 100, nm(po[..., 1]), nm(po[..., 2]), po[..., 3] / (2 * np.pi),
+                        po[..., 4] * 0.7 / 30, po[..., 5] * 0.7 / 15], -1).flatten(2)
+    road = torch.cat([nm(ro[..., 0:1]), nm(ro[..., 1:2]), ro[..., 2:5] / 100, ro[..., 5:6] / (2 * np.pi),
+                      torch.nn.functional.one_hot(ro[..., 6].long(), 7).float()], -1).flatten(2)
+    ref = torch.cat([ego, part, road], -1)
+    assert torch.allclose(out, ref, atol=3e-7, rtol=1e-6)  # GPU torch multiplies by 1/scalar: last-bit differences
+    gpu.close()
+
+
 def test_free_running_flags_stay_exact(oracle_mod):
     """No teacher forcing: 91 steps + reset + 30 steps; int tensors must stay bit-exact."""
     kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
