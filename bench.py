@@ -44,6 +44,8 @@ def params_for(workload):
               dynamicsModel=0, roadObservationAlgorithm=0, isStaticAgentControlled=1,
               initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
     kw["polylineReductionThreshold"] = 0.0 if workload == "synthetic" else 0.1
+    if workload == "lidar":  # BASELINE configs[4]: LiDAR 3 x 50 rays, mixed vehicle / cyclist / pedestrian agents
+        kw["enableLidar"] = 1
     return kw
 
 
@@ -55,7 +57,7 @@ def scenes_for(workload, worlds, rank):
     return sharding.scene_list_for_rank(WAYMO, worlds, rank)
 
 
-def make_sim(scenes, kw, agents, device_index, knn_order=0):
+def make_sim(scenes, kw, agents, device_index, knn_order=0, lidar_half_angle=0.0):
     import madrona_gpudrive as mg
     p = mg.Parameters()
     for k, v in kw.items():
@@ -64,7 +66,7 @@ def make_sim(scenes, kw, agents, device_index, knn_order=0):
         else:
             setattr(p, k, v)
     return mg.SimManager(exec_mode=mg.madrona.ExecMode.CUDA, gpu_id=device_index, scenes=scenes, params=p,
-                         max_agents=agents, knn_order=knn_order)
+                         max_agents=agents, knn_order=knn_order, lidar_half_angle=lidar_half_angle)
 
 
 def action_batches(worlds, agents, device, seed, n=8):
@@ -92,7 +94,8 @@ def bench_workload(workload, args, rank, local_rank, world, device):
     kw = params_for(workload)
     scenes = scenes_for(workload, args.worlds, rank)
     t0 = time.time()
-    sim = make_sim(scenes, kw, args.agents, local_rank, knn_order=args.knn_order)
+    sim = make_sim(scenes, kw, args.agents, local_rank, knn_order=args.knn_order,
+                   lidar_half_angle=float(np.pi) if workload == "lidar" else 0.0)  # 360 degrees
     torch.cuda.synchronize(device)
     init_s = time.time() - t0
     shape = sim.shape_tensor().to_torch().cpu().numpy()
@@ -123,6 +126,8 @@ def bench_workload(workload, args, rank, local_rank, world, device):
     run_steps(sim, batches, all_worlds, args.roofline_steps, start=k)
     torch.cuda.synchronize(device)
     names = {0: "k_world_step", 1: "k_map_obs"}
+    if workload == "lidar":
+        names[2] = "k_lidar"
     kt = {}
     for kid, name in names.items():
         ms, n = sim.kernel_timing_read(kid)
@@ -189,15 +194,21 @@ def main():
     ap.add_argument("--worlds", type=int, default=1024, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=64, choices=(64, 128))
     ap.add_argument("--roofline-steps", type=int, default=40)
-    ap.add_argument("--workloads", default="synthetic,waymo")
+    ap.add_argument("--workloads", default="synthetic,waymo,lidar",
+                    help="first = primary; synthetic | waymo | lidar (Waymo tiles + 360-degree LiDAR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default=None, choices=(None, "nccl", "gloo"),
+                    help="default: nccl (RCCL); gloo + --single-device rehearses the N>1 path on one GPU")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--knn-order", type=int, default=0, choices=(0, 1),
                     help="0 = reference heap order (default, elementwise parity); 1 = same row set, road-index order")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the step path has no CPU fallback")
-    rank, local_rank, world = sharding.init_process_group()
+    rank, local_rank, world = sharding.init_process_group(backend=args.dist_backend)
+    if args.single_device:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     device = torch.device("cuda", local_rank)

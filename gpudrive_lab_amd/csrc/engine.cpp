@@ -110,10 +110,10 @@ struct gd_sim {
     int ring_pos = 0;
     // kernel timing
     bool timing = false;
-    std::vector<EventPair> ev_pool[3];
-    size_t ev_used[3] = {0, 0, 0};
-    double ev_ms[3] = {0, 0, 0};
-    int64_t ev_launches[3] = {0, 0, 0};
+    std::vector<EventPair> ev_pool[gd::KERNEL_TIMED];
+    size_t ev_used[gd::KERNEL_TIMED] = {};
+    double ev_ms[gd::KERNEL_TIMED] = {};
+    int64_t ev_launches[gd::KERNEL_TIMED] = {};
 
     ~gd_sim() {
         if (stream || true) (void)hipDeviceSynchronize();
@@ -156,7 +156,7 @@ struct gd_sim {
     }
 
     void launch(int which, bool move) {
-        const bool timed = timing && which <= gd::KERNEL_PARTNER;
+        const bool timed = timing && which < gd::KERNEL_TIMED;
         EventPair ep{};
         if (timed) {
             if (ev_used[which] == ev_pool[which].size()) {
@@ -171,7 +171,9 @@ struct gd_sim {
             ep = ev_pool[which][ev_used[which]++];
             HIP_CHECK(hipEventRecord(ep.start, stream));
         }
-        gd::launch_kernel(d, stream, which, move);
+        if (which == gd::KERNEL_BEV) gd::launch_bev(d, stream);
+        else if (which == gd::KERNEL_LIDAR) gd::launch_lidar(d, stream);
+        else gd::launch_kernel(d, stream, which, move);
         if (timed) HIP_CHECK(hipEventRecord(ep.stop, stream));
         HIP_CHECK(hipGetLastError());
     }
@@ -181,12 +183,10 @@ struct gd_sim {
         launch(gd::KERNEL_STATE, move);
         if (!params.disableClassicalObs) launch(gd::KERNEL_MAP_OBS, move);
         if (!params.disableClassicalObs && d.bev) {  // collectBevObservationsSystem, src/sim.cpp:879-884 (opt-in)
-            gd::launch_bev(d, stream);
-            HIP_CHECK(hipGetLastError());
+            launch(gd::KERNEL_BEV, move);
         }
         if (params.enableLidar) {  // lidarSystem, src/sim.cpp:895-913
-            gd::launch_lidar(d, stream);
-            HIP_CHECK(hipGetLastError());
+            launch(gd::KERNEL_LIDAR, move);
         }
     }
 
@@ -617,7 +617,7 @@ int gd_kernel_timing_enable(gd_sim *s, int32_t enable) {
     if (!s) return fail(GD_ERR_INVALID, "null sim");
     return guarded([&]() {
         HIP_CHECK(hipStreamSynchronize(s->stream));
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < gd::KERNEL_TIMED; k++) {
             s->collect_timing(k);
             s->ev_ms[k] = 0;
             s->ev_launches[k] = 0;
@@ -627,7 +627,7 @@ int gd_kernel_timing_enable(gd_sim *s, int32_t enable) {
 }
 
 int gd_kernel_timing_read(gd_sim *s, int32_t kernel, double *total_ms, int64_t *launches) {
-    if (!s || kernel < 0 || kernel > 2) return fail(GD_ERR_INVALID, "gd_kernel_timing_read: bad argument");
+    if (!s || kernel < 0 || kernel >= gd::KERNEL_TIMED) return fail(GD_ERR_INVALID, "gd_kernel_timing_read: bad argument");
     return guarded([&]() {
         HIP_CHECK(hipStreamSynchronize(s->stream));
         s->collect_timing(kernel);

@@ -8,7 +8,8 @@
 
 namespace gd {
 
-enum { KERNEL_STATE = 0, KERNEL_MAP_OBS = 1, KERNEL_PARTNER = 2, KERNEL_RESET = 3, KERNEL_PADDING = 4 };
+// the first four are the timed kernels of gd_kernel_timing_read
+enum { KERNEL_STATE = 0, KERNEL_MAP_OBS = 1, KERNEL_LIDAR = 2, KERNEL_BEV = 3, KERNEL_RESET = 4, KERNEL_PADDING = 5, KERNEL_TIMED = 4 };
 
 // Per-world broadphase grid header (see HostWorld in scene.hpp).
 struct GridHdr {

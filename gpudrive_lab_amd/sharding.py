@@ -48,23 +48,30 @@ def scene_list_for_rank(all_scenes, worlds_per_rank, rank):
     return [all_scenes[(start + i) % n] for i in range(worlds_per_rank)]
 
 
+def _collective_device(device):
+    """RCCL reduces device tensors; gloo (CPU tests, single-GPU rehearsals) reduces host tensors."""
+    if dist.is_initialized() and dist.get_backend() == "nccl" and device is not None and device.type == "cuda":
+        return device
+    return torch.device("cpu")
+
+
 def barrier(device=None):
     if dist.is_initialized():
-        if device is not None and device.type == "cuda":
+        if dist.get_backend() == "nccl" and device is not None and device.type == "cuda":
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
 
 
 def reduce_max(value, device):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_collective_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def reduce_sum(value, device):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_collective_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

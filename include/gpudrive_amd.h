@@ -161,7 +161,7 @@ int gd_sync(gd_sim *sim);
 int gd_set_stream(gd_sim *sim, void *stream);
 
 /* Timing hooks for the bench: HIP events around the named kernel on the engine's stream.
- * kernel: 0 = state step, 1 = road observation, 2 = partner observation. */
+ * kernel: 0 = state step, 1 = road observation, 2 = LiDAR, 3 = BEV. */
 int gd_kernel_timing_enable(gd_sim *sim, int32_t enable);
 int gd_kernel_timing_read(gd_sim *sim, int32_t kernel, double *total_ms, int64_t *launches);
 
