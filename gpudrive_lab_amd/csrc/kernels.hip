@@ -178,8 +178,10 @@ __global__ __launch_bounds__(A_T) void k_init_padding_rows(DevSim d) {
 // state step: movement -> collision -> reward -> --t -> done -> self/abs/partner observations
 // (src/sim.cpp:294-383, 628-747, 560-626, 168-240, 769-783; task order :785-958)
 // ------------------------------------------------------------------------------------------
+constexpr int STEP_THREADS = 256;  // agents live on threads [0, A); all threads write partner rows
+
 template <int A_T, bool MOVE>
-__global__ __launch_bounds__(A_T) void k_world_step(DevSim d) {
+__global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     const int w = blockIdx.x, a = threadIdx.x;
     const int n = d.shape[w * 2 + 0];
     const size_t i = (size_t)w * A_T + a;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(A_T) void k_world_step(DevSim d) {
     __syncthreads();
 
     // ---- collisionDetectionSystem over broadphase candidates, src/sim.cpp:628-747, 792-801 ----
-    if (live && active) {
+    if (live && active && !(d.debug_flags & 16)) {
         Obb me;
         {
             float *mf = reinterpret_cast<float *>(&me);
@@ -397,10 +399,10 @@ __global__ __launch_bounds__(A_T) void k_world_step(DevSim d) {
 
     // ---- collectPartnerObsSystem, :188-240.  One thread per (ego, slot) row so that a wave
     // writes 64 consecutive 36-byte rows. ----
-    if (!d.p.disableClassicalObs) {
+    if (!d.p.disableClassicalObs && !(d.debug_flags & 8)) {
         const int rows = n * (A_T - 1);
         float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
-        for (int p = a; p < rows; p += A_T) {
+        for (int p = a; p < rows; p += STEP_THREADS) {
             const int ego = p / (A_T - 1), k = p - ego * (A_T - 1);
             float *o = base + (size_t)p * 9;
             if (k >= n - 1) {  // zero_nonexist(): id -2
@@ -437,8 +439,8 @@ static void launch_all(const DevSim &d, hipStream_t st, int which, bool move) {
     case KERNEL_RESET: hipLaunchKernelGGL(k_reset_worlds<A_T>, grid, block, 0, st, d); break;
     case KERNEL_PADDING: hipLaunchKernelGGL(k_init_padding_rows<A_T>, grid, block, 0, st, d); break;
     case KERNEL_STATE:
-        if (move) hipLaunchKernelGGL((k_world_step<A_T, true>), grid, block, 0, st, d);
-        else hipLaunchKernelGGL((k_world_step<A_T, false>), grid, block, 0, st, d);
+        if (move) hipLaunchKernelGGL((k_world_step<A_T, true>), grid, dim3(STEP_THREADS), 0, st, d);
+        else hipLaunchKernelGGL((k_world_step<A_T, false>), grid, dim3(STEP_THREADS), 0, st, d);
         break;
     case KERNEL_MAP_OBS: launch_map_obs(d, st); break;
     }

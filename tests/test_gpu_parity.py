@@ -229,6 +229,38 @@ def test_packed_observations_match_reference_python_golden():
     gpu.close()
 
 
+EDGE_SCENES = [
+    # (name, n_agents, n_polylines, pts_per_polyline)  ->  road entities = n_polylines * (pts - 1)
+    ("roads_below_K", 5, 3, 51),         # R = 150 < K: no heap, radius filter + zero fill only
+    ("roads_equal_K", 7, 4, 51),         # R = 200 == K: make_heap, no inserts
+    ("roads_K_plus_1", 7, 1, 202),       # R = 201: exactly one candidate
+    ("no_roads", 4, 0, 2),               # empty road list
+    ("single_agent", 1, 8, 65),          # N = 1: all partner rows are the id -2 padding
+    ("more_objects_than_slots", 90, 6, 65),   # 90 objects, 64 agent slots
+    ("road_cap", 6, 40, 301),            # 12,000 segments: capped at kMaxRoadEntityCount = 10,000
+]
+
+
+@pytest.mark.parametrize("name,n_agents,n_poly,pts", EDGE_SCENES, ids=[c[0] for c in EDGE_SCENES])
+@pytest.mark.parametrize("road_alg", [0, 1], ids=["knn", "linear"])
+def test_edge_case_scenes(oracle_mod, tmp_path, name, n_agents, n_poly, pts, road_alg):
+    """Ragged / empty / maximum-size inputs, both road algorithms, reference row order."""
+    import json
+    from gpudrive_lab_amd import synth
+    path = tmp_path / (name + ".json")
+    path.write_text(json.dumps(synth.make_scene(17, n_agents=n_agents, n_polylines=n_poly, pts_per_polyline=pts)))
+    kw = dict(polylineReductionThreshold=0.0, observationRadius=40.0, collisionBehaviour=0, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, roadObservationAlgorithm=road_alg, **ALL_OBJECTS)
+    scenes = [str(path), SCENE_407]  # ragged batch: the edge world next to an ordinary one
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    shape = np.asarray(orc.shape_tensor())
+    assert shape[0, 0] == min(n_agents, 64) and shape[0, 1] == min(n_poly * (pts - 1), 10000)
+    P.compare_fresh(gpu, orc)
+    P.lockstep(gpu, orc, 4, 0, seed=21)
+    gpu.close()
+
+
 def test_free_running_flags_stay_exact(oracle_mod):
     """No teacher forcing: 91 steps + reset + 30 steps; int tensors must stay bit-exact."""
     kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
