@@ -481,11 +481,27 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         const size_t i = (size_t)w * A_T + a;
         const float ex = d.px[i], ey = d.py[i];
         const Quat inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
-        // gather the in-radius candidates (key, road) in road order
+        // gather the in-radius candidates (key, road) in road order.  The agent's mask words are
+        // fetched up front, 64 chunks per register (one L2 latency), and then broadcast per chunk pair
+        // with v_readlane: no dependent global load in the loop.
+        constexpr int MW = (GD_MAX_ROAD_ENTITIES / 32 + 64) / 64;  // 5 registers cover 10,000 roads
+        unsigned int mw[MW];
+#pragma unroll
+        for (int q = 0; q < MW; q++) {
+            const int c = q * 64 + lane;
+            mw[q] = c < nchunks ? mask[(size_t)c * A_T + a] : 0u;
+        }
         int nin = 0;
         for (int rb = 0; rb < R; rb += 64) {
-            const unsigned int w0 = mask[(size_t)(rb >> 5) * A_T + a];
-            const unsigned int w1 = (rb + 32 < R) ? mask[(size_t)((rb >> 5) + 1) * A_T + a] : 0u;
+            const int c0 = rb >> 5;  // even chunk index; c0 and c0+1 live in the same register
+            unsigned int w0 = 0u, w1 = 0u;
+#pragma unroll
+            for (int q = 0; q < MW; q++) {
+                if ((c0 >> 6) == q) {  // wave-uniform
+                    w0 = (unsigned int)__builtin_amdgcn_readlane((int)mw[q], c0 & 63);
+                    w1 = (unsigned int)__builtin_amdgcn_readlane((int)mw[q], (c0 + 1) & 63);
+                }
+            }
             if ((w0 | w1) == 0u) continue;  // wave-uniform
             const int r = rb + lane;
             const bool in = ((lane < 32 ? w0 : w1) >> (lane & 31)) & 1u;
