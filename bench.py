@@ -138,8 +138,19 @@ def bench_workload(workload, args, rank, local_rank, world, device):
     avg_s = kt["k_map_obs"]["avg_us"] * 1e-6
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     res["kernels"] = kt
+    # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command
+    # (tools/profile.sh, committed under profiles/); counters cannot be read from inside the process.
+    traffic = None
+    try:
+        tkey = ("set_" if args.knn_order == 1 else "exact_") + workload if workload != "lidar" else "lidar"
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            traffic = json.load(fh).get(tkey, {}).get("hbm_bytes_per_launch")
+        if args.worlds != 1024 or args.agents != 64:
+            traffic = None
+    except Exception:
+        traffic = None
     res["roofline"] = dict(bound="hbm", kernel="k_map_obs", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                           frac=achieved / HBM_PEAK_GBS, traffic=None,
+                           frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                            algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt["k_map_obs"]["avg_us"])
     sim.close()
     return res
