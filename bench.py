@@ -91,6 +91,13 @@ def run_steps(sim, batches, all_worlds, n, start=0):
 
 
 def bench_workload(workload, args, rank, local_rank, world, device):
+    # everything (action writes, steps, resets) runs on one side stream: the engine replays its step as
+    # a hipGraph there (the legacy null stream cannot be captured)
+    with torch.cuda.stream(torch.cuda.Stream(device=device)):
+        return _bench_workload(workload, args, rank, local_rank, world, device)
+
+
+def _bench_workload(workload, args, rank, local_rank, world, device):
     kw = params_for(workload)
     scenes = scenes_for(workload, args.worlds, rank)
     t0 = time.time()

@@ -116,7 +116,8 @@ struct gd_sim {
     int64_t ev_launches[gd::KERNEL_TIMED] = {};
 
     ~gd_sim() {
-        if (stream || true) (void)hipDeviceSynchronize();
+        (void)hipDeviceSynchronize();
+        if (step_graph) (void)hipGraphExecDestroy(step_graph);
         for (int i = 0; i < GD_T_COUNT; i++)
             if (owned[i] && exported[i]) (void)hipFree(exported[i]);
         for (void *p : internal) (void)hipFree(p);
@@ -178,6 +179,52 @@ struct gd_sim {
         HIP_CHECK(hipGetLastError());
     }
 
+    // The Step task graph as one hipGraph: the kernels of a step are captured once on the engine's
+    // stream and replayed with a single hipGraphLaunch (the kernel arguments are the DevSim struct by
+    // value, so any change of it -- rebuilt worlds, a new stream, timing mode -- drops the graph).
+    hipGraphExec_t step_graph = nullptr;
+    bool graph_ok = std::getenv("GPUDRIVE_NO_GRAPH") == nullptr;
+
+    void drop_graph() {
+        if (step_graph) {
+            (void)hipGraphExecDestroy(step_graph);
+            step_graph = nullptr;
+        }
+    }
+
+    void step() {
+        if (!graph_ok || timing || stream == nullptr) {  // the legacy null stream cannot be captured
+            run_rest(true);
+            return;
+        }
+        if (!step_graph) {
+            hipGraph_t g = nullptr;
+            if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+                (void)hipGetLastError();
+                graph_ok = false;
+                run_rest(true);
+                return;
+            }
+            try {
+                run_rest(true);
+            } catch (...) {
+                (void)hipStreamEndCapture(stream, &g);
+                if (g) (void)hipGraphDestroy(g);
+                throw;
+            }
+            HIP_CHECK(hipStreamEndCapture(stream, &g));
+            const hipError_t e = hipGraphInstantiate(&step_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) {  // fall back to plain launches for good
+                step_graph = nullptr;
+                graph_ok = false;
+                run_rest(true);
+                return;
+            }
+        }
+        HIP_CHECK(hipGraphLaunch(step_graph, stream));
+    }
+
     // setupRestOfTasks, src/sim.cpp:785-943
     void run_rest(bool move) {
         launch(gd::KERNEL_STATE, move);
@@ -204,6 +251,7 @@ struct gd_sim {
     // src/level_gen.cpp:396-465).
     void rebuild_worlds(const std::vector<int> &worlds) {
         HIP_CHECK(hipStreamSynchronize(stream));
+        drop_graph();
         std::map<std::string, std::shared_ptr<const gd::SceneMap>> scene_cache;
         std::map<std::string, std::shared_ptr<gd::HostWorld>> world_cache;
         std::vector<int32_t> rebuilt(W, 0);
@@ -554,7 +602,7 @@ void gd_destroy(gd_sim *sim) { delete sim; }
 
 int gd_step(gd_sim *s) {
     if (!s) return fail(GD_ERR_INVALID, "gd_step: null sim");
-    return guarded([&]() { s->run_rest(true); });
+    return guarded([&]() { s->step(); });
 }
 
 int gd_reset(gd_sim *s, const int32_t *idx, int32_t n) {
@@ -637,6 +685,7 @@ int gd_set_stream(gd_sim *s, void *stream) {
     if (!s) return fail(GD_ERR_INVALID, "gd_set_stream: null sim");
     return guarded([&]() {
         HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->drop_graph();
         s->stream = static_cast<hipStream_t>(stream);
     });
 }

@@ -261,6 +261,25 @@ def test_edge_case_scenes(oracle_mod, tmp_path, name, n_agents, n_poly, pts, roa
     gpu.close()
 
 
+def test_parity_on_a_side_stream_with_graph_replay(oracle_mod):
+    """On a non-default torch stream the engine captures the step into a hipGraph and replays it;
+    results must not change (and the stream hand-over through gd_set_stream must work)."""
+    import torch
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
+              distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
+    scenes = [SCENE_4, TEST_JSON]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)      # built on the default stream
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        P.lockstep(gpu, orc, 12, 0, seed=31)               # first step captures, the rest replay
+        gpu.set_maps([TEST_JSON, SCENE_407])               # rebuild drops the graph
+        orc.set_maps([TEST_JSON, SCENE_407])
+        P.compare_fresh(gpu, orc)
+        P.lockstep(gpu, orc, 4, 0, seed=32)
+    P.lockstep(gpu, orc, 3, 0, seed=33)                    # back on the default stream
+    gpu.close()
+
+
 def test_free_running_flags_stay_exact(oracle_mod):
     """No teacher forcing: 91 steps + reset + 30 steps; int tensors must stay bit-exact."""
     kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
