@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_bev(DevSim d) {
 // Madrona's absent 3-D BVH; the geometry is restated from the collision meshes' extents exactly as
 // in oracle/gd_oracle.c (lidar_system): horizontal rays see the entities whose scaled z-range
 // contains the ray height, as 2-D boxes; a box containing the origin is not hit.
-// Entity-major: every thread takes entities, culls by range and by the angular interval the
+// Entity-major: every lane takes entities, culls by range and by the angular interval the
 // entity's bounding circle subtends, runs the slab test only for the rays inside it, and keeps the
 // nearest hit per (plane, ray) with a 64-bit LDS atomicMin on (t bits, entity order).
 // ------------------------------------------------------------------------------------------
@@ -187,100 +187,164 @@ __device__ __forceinline__ bool ray_box(float ox, float oy, float dx, float dy, 
 
 template <int A_T>
 __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
+    // One workgroup per world, one wave per agent at a time (agents wave, wave+4, ...): a grid of
+    // (agents x worlds) tiny workgroups spent most of its time in workgroup launch/teardown.
     constexpr int NS = GD_NUM_LIDAR_SAMPLES;
-    const int a = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int n = d.shape[w * 2 + 0];
-    if (a >= n) return;
     const int r0 = d.road_off[w];
     const int R = d.road_off[w + 1] - r0;
-    const size_t i = (size_t)w * A_T + a;
 
-    __shared__ unsigned long long s_best[3 * NS];
-    __shared__ float s_x[NS], s_y[NS], s_dx[NS], s_dy[NS];
+    constexpr int HEAVY_CAP = 256;
+    __shared__ unsigned long long s_best[4][3 * NS];
+    __shared__ int s_heavy[4][HEAVY_CAP];
+    __shared__ float s_x[4][NS], s_y[4][NS], s_dx[4][NS], s_dy[4][NS];
 
-    const float ox = d.px[i], oy = d.py[i], oz = d.pz[i];
-    const Quat rot = quat_from_wz(d.qw[i], d.qz[i]);
-    const Quat inv = quat_inv(rot);
     const float half = d.lidar_half_angle > 0.f ? d.lidar_half_angle : kPi / 3;
-    const float head_angle = d.controlled[i] ? d.action[i * 10 + 2] : 0.f;
+    const float step = 2.f * half / (float)NS;  // angle between neighbouring rays
     const float offs[3] = {0.5f, 0.1f, -0.1f};  // src/consts.hpp:42-44
 
-    if (tid < NS) {
-        const float theta = half * (2 * (float)tid / (float)NS - 1) + head_angle;
-        const float x = p_cos(theta), y = p_sin(theta);
-        const V3 fwd = quat_rotate(rot, V3{0.f, 1.f, 0.f}), right = quat_rotate(rot, V3{1.f, 0.f, 0.f});
-        V3 rd{x * right.x + y * fwd.x, x * right.y + y * fwd.y, x * right.z + y * fwd.z};
-        const float invl = 1.f / sqrtf(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z);
-        s_x[tid] = x; s_y[tid] = y;
-        s_dx[tid] = rd.x * invl; s_dy[tid] = rd.y * invl;
-    }
-    if (tid < 3 * NS) s_best[tid] = ~0ull;
-    __syncthreads();
+    for (int a = wave; a < n; a += 4) {
+        const size_t i = (size_t)w * A_T + a;
+        const float ox = d.px[i], oy = d.py[i], oz = d.pz[i];
+        const Quat rot = quat_from_wz(d.qw[i], d.qz[i]);
+        const Quat inv = quat_inv(rot);
+        const float head_angle = d.controlled[i] ? d.action[i * 10 + 2] : 0.f;
+        unsigned long long *best = s_best[wave];
+        if (lane < NS) {
+            const float theta = half * (2 * (float)lane / (float)NS - 1) + head_angle;
+            const float x = p_cos(theta), y = p_sin(theta);
+            const V3 fwd = quat_rotate(rot, V3{0.f, 1.f, 0.f}), right = quat_rotate(rot, V3{1.f, 0.f, 0.f});
+            V3 rd{x * right.x + y * fwd.x, x * right.y + y * fwd.y, x * right.z + y * fwd.z};
+            const float invl = 1.f / sqrtf(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z);
+            s_x[wave][lane] = x; s_y[wave][lane] = y;
+            s_dx[wave][lane] = rd.x * invl; s_dy[wave][lane] = rd.y * invl;
+        }
+        for (int t = lane; t < 3 * NS; t += 64) best[t] = ~0ull;
+        int nheavy = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    const float step = 2.f * half / (float)NS;  // angle between neighbouring rays
-    for (int e = tid; e < n + R; e += 256) {
-        float cx, cy, hx, hy, zlo, zhi;
-        Quat q;
-        if (e < n) {
-            if (e == a) continue;
-            const size_t oi = (size_t)w * A_T + e;
-            cx = d.px[oi]; cy = d.py[oi];
-            q = quat_from_wz(d.qw[oi], d.qz[oi]);
-            hx = d.sc0[oi]; hy = d.sc1[oi];
-            zlo = d.pz[oi]; zhi = d.pz[oi] + 2 * GD_VEHICLE_SCALE;  // agent mesh z in [0,2], Scale d2 = 0.7
-        } else {
-            const int r = r0 + (e - n);
-            const float2 xy = d.road_xy[r];
-            const float4 a0 = d.road_aux[(size_t)r * 2], a1 = d.road_aux[(size_t)r * 2 + 1];
-            cx = xy.x; cy = xy.y;
-            q = quat_from_wz(a0.x, a0.y);
-            hx = a0.z; hy = a0.w;
-            const int type = (int)a1.y;
-            const float zc = type == ET_RoadEdge ? 1 + 0.1f : (type == ET_StopSign ? 1.f : 1 + -0.1f);
-            zlo = zc - a1.x; zhi = zc + a1.x;  // cube mesh z in [-1,1] scaled by d2
-        }
-        int planes = 0;
+        for (int eb = 0; eb < n + R; eb += 64) {  // uniform trip count: the ballot below needs every lane
+            const int e = eb + lane;
+            float cx = 0.f, cy = 0.f, hx = 0.f, hy = 0.f, zlo = 1.f, zhi = 0.f;
+            Quat q{1.f, 0.f, 0.f, 0.f};
+            bool valid = e < n + R && e != a;
+            if (valid && e < n) {
+                const size_t oi = (size_t)w * A_T + e;
+                cx = d.px[oi]; cy = d.py[oi];
+                q = quat_from_wz(d.qw[oi], d.qz[oi]);
+                hx = d.sc0[oi]; hy = d.sc1[oi];
+                zlo = d.pz[oi]; zhi = d.pz[oi] + 2 * GD_VEHICLE_SCALE;  // agent mesh z in [0,2], Scale d2 = 0.7
+            } else if (valid) {
+                const int r = r0 + (e - n);
+                const float2 xy = d.road_xy[r];
+                const float4 a0 = d.road_aux[(size_t)r * 2], a1 = d.road_aux[(size_t)r * 2 + 1];
+                cx = xy.x; cy = xy.y;
+                q = quat_from_wz(a0.x, a0.y);
+                hx = a0.z; hy = a0.w;
+                const int type = (int)a1.y;
+                const float zc = type == ET_RoadEdge ? 1 + 0.1f : (type == ET_StopSign ? 1.f : 1 + -0.1f);
+                zlo = zc - a1.x; zhi = zc + a1.x;  // cube mesh z in [-1,1] scaled by d2
+            }
+            int planes = 0;
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
-            const float rz = oz + offs[p];
-            if (rz >= zlo && rz <= zhi) planes |= 1 << p;
-        }
-        if (!planes) continue;
-        const V2 rel = ego_relative(ox, oy, inv, cx, cy);
-        const float rho = len_2(rel.x, rel.y), rb = sqrtf(hx * hx + hy * hy);
-        if (rho > 200.f + rb) continue;
-        // candidate rays: theta_idx = -half + idx*step + head_angle within phi +- alpha (+ slack), all wraps
-        const float phi = atan2f(rel.y, rel.x) - head_angle;
-        const float alpha = (rho <= rb ? kPi : asinf(fminf(1.f, rb / rho))) + 0.02f;
-        for (int kwrap = -1; kwrap <= 1; kwrap++) {
-            const float c = phi + kwrap * kPiM2;
-            int lo_i = (int)floorf((c - alpha + half) / step) - 1, hi_i = (int)ceilf((c + alpha + half) / step) + 1;
-            lo_i = max(lo_i, 0);
-            hi_i = min(hi_i, NS - 1);
-            for (int idx = lo_i; idx <= hi_i; idx++) {
-                float t;
-                if (!ray_box(ox, oy, s_dx[idx], s_dy[idx], cx, cy, q, hx, hy, t)) continue;
-                if (!(t <= 200.f)) continue;
-                const unsigned long long packed = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)e;
+            for (int p = 0; p < 3; p++) {
+                const float rz = oz + offs[p];
+                if (rz >= zlo && rz <= zhi) planes |= 1 << p;
+            }
+            valid = valid && planes != 0;
+            const V2 rel = ego_relative(ox, oy, inv, cx, cy);
+            const float rho = len_2(rel.x, rel.y), rb = sqrtf(hx * hx + hy * hy);
+            valid = valid && !(rho > 200.f + rb);
+            // candidate rays: theta_idx = -half + idx*step + head_angle within phi +- alpha (+ slack), all wraps
+            const float phi = atan2f(rel.y, rel.x) - head_angle;
+            const float alpha = (rho <= rb ? kPi : asinf(fminf(1.f, rb / rho))) + 0.02f;
+            int lo_w[3], hi_w[3], nrays = 0;
 #pragma unroll
-                for (int p = 0; p < 3; p++)
-                    if (planes & (1 << p)) atomicMin(&s_best[p * NS + idx], packed);
+            for (int kw = 0; kw < 3; kw++) {
+                const float c = phi + (kw - 1) * kPiM2;
+                lo_w[kw] = max((int)floorf((c - alpha + half) / step) - 1, 0);
+                hi_w[kw] = min((int)ceilf((c + alpha + half) / step) + 1, NS - 1);
+                nrays += max(hi_w[kw] - lo_w[kw] + 1, 0);
+            }
+            // Entities that subtend many rays (close ones) would make the whole wave loop 50 times for a
+            // few lanes: they go to a per-wave list and are traced afterwards with one LANE PER RAY.
+            const bool heavy = valid && nrays > 6;
+            const unsigned long long hb = __ballot(heavy);
+            if (heavy) {
+                const int pos = nheavy + __popcll(hb & ((1ull << lane) - 1ull));
+                if (pos < HEAVY_CAP) s_heavy[wave][pos] = (planes << 28) | e;
+            }
+            const bool overflow = heavy && nheavy + __popcll(hb & ((1ull << lane) - 1ull)) >= HEAVY_CAP;
+            nheavy = min(nheavy + __popcll(hb), HEAVY_CAP);
+            if (!valid || (heavy && !overflow)) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++) {
+                for (int idx = lo_w[kw]; idx <= hi_w[kw]; idx++) {
+                    float t;
+                    if (!ray_box(ox, oy, s_dx[wave][idx], s_dy[wave][idx], cx, cy, q, hx, hy, t)) continue;
+                    if (!(t <= 200.f)) continue;
+                    const unsigned long long packed = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)e;
+#pragma unroll
+                    for (int p = 0; p < 3; p++)
+                        if (planes & (1 << p)) atomicMin(&best[p * NS + idx], packed);
+                }
             }
         }
-    }
-    __syncthreads();
-    if (tid < 3 * NS) {
-        const unsigned long long b = s_best[tid];
-        float *o = d.lidar + (i * 3 * NS + tid) * 4;
-        if (b == ~0ull) {
-            o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
-        } else {
-            const float t = __uint_as_float((unsigned int)(b >> 32));
-            const int e = (int)(b & 0xffffffffu);
-            const int type = e < n ? d.etype[(size_t)w * A_T + e] : (int)d.road_aux[(size_t)(r0 + e - n) * 2 + 1].y;
-            const int idx = tid % NS;
-            o[0] = t; o[1] = (float)type; o[2] = t * s_x[idx]; o[3] = t * s_y[idx];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // heavy entities: lane = ray
+        for (int h = 0; h < nheavy; h++) {
+            const int packed_e = s_heavy[wave][h];
+            const int e = packed_e & 0x0fffffff, planes = (packed_e >> 28) & 7;
+            float cx, cy, hx, hy;
+            Quat q;
+            if (e < n) {
+                const size_t oi = (size_t)w * A_T + e;
+                cx = d.px[oi]; cy = d.py[oi];
+                q = quat_from_wz(d.qw[oi], d.qz[oi]);
+                hx = d.sc0[oi]; hy = d.sc1[oi];
+            } else {
+                const int r = r0 + (e - n);
+                const float2 xy = d.road_xy[r];
+                const float4 a0 = d.road_aux[(size_t)r * 2];
+                cx = xy.x; cy = xy.y;
+                q = quat_from_wz(a0.x, a0.y);
+                hx = a0.z; hy = a0.w;
+            }
+            if (lane < NS) {
+                float t;
+                if (ray_box(ox, oy, s_dx[wave][lane], s_dy[wave][lane], cx, cy, q, hx, hy, t) && t <= 200.f) {
+                    const unsigned long long packed = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)e;
+#pragma unroll
+                    for (int p = 0; p < 3; p++)
+                        if ((planes & (1 << p)) && packed < best[p * NS + lane]) best[p * NS + lane] = packed;
+                }
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int t = lane; t < 3 * NS; t += 64) {
+            const unsigned long long b = best[t];
+            float *o = d.lidar + (i * 3 * NS + t) * 4;
+            if (b == ~0ull) {
+                o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+            } else {
+                const float tt = __uint_as_float((unsigned int)(b >> 32));
+                const int e = (int)(b & 0xffffffffu);
+                const int type = e < n ? d.etype[(size_t)w * A_T + e] : (int)d.road_aux[(size_t)(r0 + e - n) * 2 + 1].y;
+                const int idx = t % NS;
+                o[0] = tt; o[1] = (float)type; o[2] = tt * s_x[wave][idx]; o[3] = tt * s_y[wave][idx];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
 
@@ -293,7 +357,7 @@ void launch_bev(const DevSim &d, hipStream_t st) {
 }
 
 void launch_lidar(const DevSim &d, hipStream_t st) {
-    const dim3 grid(d.A, d.W);
+    const dim3 grid(d.W);
     if (d.A == 64) hipLaunchKernelGGL(k_lidar<64>, grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL(k_lidar<128>, grid, dim3(256), 0, st, d);
 }
