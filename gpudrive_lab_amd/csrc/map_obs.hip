@@ -137,67 +137,79 @@ struct HeapCol {
             ck[l + 1] = left2 ? hl : hr;
             ph[l + 2] = d2 - (left2 ? 1 : 0);
         }
+        // 7th level iff the level-6 node has children.  Without it the reads are clamped into the
+        // array, ck[6] = -1 lets x rest at level 6 at the latest, and the level-7 store repeats level 6.
         const int second6 = 2 * ph[6] + 2;
         const bool has7 = second6 < K - 1;
-        ck[6] = 0.f; ci[6] = 0; ph[7] = 0;
-        if (has7) {
-            const float kr = key(second6), kl = key(second6 - 1);
+        {
+            const int s6 = has7 ? second6 : K - 2;
+            const float kr = key(s6), kl = key(s6 - 1);
             const bool left = kr < kl;
-            ck[6] = left ? kl : kr;
-            ph[7] = second6 - (left ? 1 : 0);
+            ck[6] = has7 ? (left ? kl : kr) : -1.f;
+            ph[7] = s6 - (left ? 1 : 0);
             ci[6] = index(ph[7]);
         }
 #pragma unroll
         for (int l = 0; l < 6; l++) ci[l] = index(ph[l + 1]);
-        const int m = has7 ? 7 : 6;
-        // level j at which x comes to rest: it climbs past level l+1 while the value now at level l is smaller
-        int j = m;
-        bool climbing = true;
+        // x (the old last element) climbs from the leaf hole past every moved child that is smaller.
+        // The moved children are non-increasing down the path (heap invariant), so "x passes level l"
+        // is the monotone predicate c[l] = ck[l] < lk and needs no serial chain:
+        //   slot ph[l] <- ck[l-1] if c[l-1]   (x went above: the child moved up stays one lower)
+        //              <- x       if c[l] && !c[l-1]
+        //              <- ck[l]   otherwise   (x rests below)
+        bool c[8];
 #pragma unroll
-        for (int l = 6; l >= 0; l--) {
-            if (l < m) {
-                climbing = climbing && (ck[l] < lk);
-                if (climbing) j = l;
-            }
-        }
-        // new contents of the path slots ph[0..m]
+        for (int l = 0; l < 7; l++) c[l] = ck[l] < lk;
+        c[7] = true;
         float nk[8];
         unsigned short ni[8];
 #pragma unroll
         for (int l = 0; l < 8; l++) {
-            const float below_k = l > 0 ? ck[l - 1] : 0.f;
-            const unsigned short below_i = l > 0 ? ci[l - 1] : (unsigned short)0;
             const float here_k = l < 7 ? ck[l] : 0.f;
             const unsigned short here_i = l < 7 ? ci[l] : (unsigned short)0;
-            nk[l] = l < j ? here_k : (l == j ? lk : below_k);
-            ni[l] = l < j ? here_i : (l == j ? li : below_i);
-            if (l <= m) set(ph[l], nk[l], ni[l]);
+            nk[l] = c[l] ? lk : here_k;
+            ni[l] = c[l] ? li : here_i;
+            if (l > 0) {
+                nk[l] = c[l - 1] ? ck[l - 1] : nk[l];
+                ni[l] = c[l - 1] ? ci[l - 1] : ni[l];
+            }
         }
+#pragma unroll
+        for (int l = 0; l < 7; l++) set(ph[l], nk[l], ni[l]);
+        set(has7 ? ph[7] : ph[6], has7 ? nk[7] : nk[6], has7 ? ni[7] : ni[6]);
         // current values of the ancestor chain of slot K-1 (patched where the pop rewrote a slot)
         float cur_k[7];
         unsigned short cur_i[7];
+        cur_k[0] = nk[0]; cur_i[0] = ni[0];
 #pragma unroll
-        for (int l = 0; l < 7; l++) {
-            const bool rewritten = ph[l] == Q[l];  // ph[l] lives on level l, like Q[l]; l <= 6 <= m
+        for (int l = 1; l < 7; l++) {
+            const bool rewritten = ph[l] == Q[l];  // ph[l] lives on level l, like Q[l]
             cur_k[l] = rewritten ? nk[l] : qk[l];
             cur_i[l] = rewritten ? ni[l] : qi[l];
         }
-        // y rests at chain position t (7 = slot K-1, l = slot Q[l]); everything below t shifts down one
-        int t = 7;
-        bool up = true;
+        // y climbs from slot K-1 along the chain; the chain is non-increasing towards the leaf, so
+        // p[u] = cur_k[u] < yk is monotone as well: chain position u (7 = slot K-1) receives
+        // cur[u-1] if p[u-1], y if p[u] && !p[u-1], and keeps its value otherwise.
+        bool p[8];
 #pragma unroll
-        for (int l = 6; l >= 0; l--) {
-            up = up && (cur_k[l] < yk);
-            if (up) t = l;
-        }
+        for (int u = 0; u < 7; u++) p[u] = cur_k[u] < yk;
+        p[7] = true;
+        float out0 = 0.f;
 #pragma unroll
         for (int u = 7; u >= 0; u--) {
             const int slot = u == 7 ? K - 1 : Q[u];
-            // (predicated stores measured faster than unconditional stores to a scratch row: 3.65 vs 3.79 ms)
-            if (u > t) set(slot, cur_k[u - 1], cur_i[u - 1]);
-            else if (u == t) set(slot, yk, yi);
+            float ok = u < 7 ? cur_k[u] : 0.f;
+            unsigned short oi = u < 7 ? cur_i[u] : (unsigned short)0;
+            ok = p[u] ? yk : ok;
+            oi = p[u] ? yi : oi;
+            if (u > 0) {
+                ok = p[u - 1] ? cur_k[u - 1] : ok;
+                oi = p[u - 1] ? cur_i[u - 1] : oi;
+            }
+            set(slot, ok, oi);
+            if (u == 0) out0 = ok;
         }
-        return t == 0 ? yk : nk[0];
+        return out0;
     }
     // radiusFilter, src/knn.hpp:83-97 (swap-remove in heap-array order); returns newBeyond
     __device__ __forceinline__ int radius_filter(int len, float radius) const {
