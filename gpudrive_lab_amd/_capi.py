@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgpudrive_amd.so")
+_SO = os.environ.get("GPUDRIVE_AMD_LIB") or os.path.join(_HERE, "libgpudrive_amd.so")  # override: developer experiments only
 _LIB = None
 
 GD_OK = 0

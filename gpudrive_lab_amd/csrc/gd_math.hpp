@@ -101,6 +101,22 @@ GD_HD V2 ego_relative(float ref_x, float ref_y, Quat ref_inv, float abs_x, float
     return V2{r.x, r.y};
 }
 
+// Squared ego-frame distance of an absolute point for a yaw-only frame: the value of
+// len2_2(ego_relative(...)) with the terms that multiply the quaternion's zero x/y components
+// dropped.  With pure = (0, 0, qz) and v = (vx, vy, 0) the general rotateVec reduces, operation
+// for operation, to  r.x = vx - 2 (qz vy w + qz (qz vx)),  r.y = vy + 2 (qz vx w - qz (qz vy));
+// a dropped term only ever adds a zero, so every finite result is identical (the sign of a zero
+// result may differ, which a squared distance cannot see).  2*A is exact, so the final
+// multiply-add is written as one fma.  `qw`, `qz` are the components of the INVERSE rotation.
+GD_HD float ego_dist2(float ref_x, float ref_y, float qw, float qz, float abs_x, float abs_y) {
+    const float vx = abs_x - ref_x, vy = abs_y - ref_y;
+    const float t = qz * vy, u = qz * vx;
+    const float A = t * qw + qz * u;
+    const float B = u * qw - qz * t;
+    const float rx = __builtin_fmaf(-2.f, A, vx), ry = __builtin_fmaf(2.f, B, vy);
+    return rx * rx + ry * ry;
+}
+
 // 2-D oriented box, reference src/obb.hpp:12-50.  14 floats.
 struct Obb {
     float cx[4], cy[4];  // corners

@@ -28,6 +28,10 @@
 #include "engine.hpp"
 #include "gd_math.hpp"
 
+#ifndef GD_EXPT
+#define GD_EXPT 0
+#endif
+
 namespace gd {
 
 namespace {
@@ -103,22 +107,22 @@ struct HeapCol {
     // second = 2h+2 <= 126 < 199, and a 7th iff the level-6 node has children, h <= 98; `second == len`
     // cannot happen: second is even, len is odd), then pushes the old last element x up from the leaf
     // hole.  The values x meets on its way up are exactly the children just moved, which are still in
-    // registers, so its final level needs no LDS read.  push_heap then lifts the new element y from
-    // slot K-1 along the fixed ancestor chain 99,49,24,11,5,2,0; those seven slots are prefetched with
-    // the first level and patched where the pop rewrote them.  One LDS round trip per sift-down level
-    // is the only dependent chain left; there are no data-dependent loops.
-    // Returns the key of the new root.
-    __device__ __forceinline__ float replace_top(float yk, unsigned short yi) const {
-        constexpr int Q[7] = {0, 2, 5, 11, 24, 49, 99};
-        const float lk = key(K - 1);
-        const unsigned short li = index(K - 1);
-        float qk[7];
-        unsigned short qi[7];
+    // registers, so its climb needs no LDS read.  push_heap then lifts the new element y from slot K-1
+    // along the fixed ancestor chain 99,49,24,11,5,2,0.  The caller keeps those seven slots in
+    // registers across calls (`qk`/`qi`, level l = slot Q[l]; load_chain() fills them); they are
+    // patched where the pop rewrote them and come back holding the chain's new contents, qk[0] being
+    // the new root key.  There are no data-dependent loops and no serial predicate chains.
+    static constexpr int Q[7] = {0, 2, 5, 11, 24, 49, 99};
+    __device__ __forceinline__ void load_chain(float (&qk)[7], unsigned int (&qi)[7]) const {
 #pragma unroll
-        for (int l = 1; l < 7; l++) { qk[l] = key(Q[l]); qi[l] = index(Q[l]); }
+        for (int l = 0; l < 7; l++) { qk[l] = key(Q[l]); qi[l] = index(Q[l]); }
+    }
+    __device__ __forceinline__ void replace_top(float yk, unsigned int yi, float (&qk)[7], unsigned int (&qi)[7]) const {
+        const float lk = key(K - 1);
+        const unsigned int li = index(K - 1);
         int ph[8];
         float ck[7];
-        unsigned short ci[7];
+        unsigned int ci[7];
         ph[0] = 0;
         // Decisions use keys only, two levels per LDS round trip: the hole's two children AND its four
         // grandchildren are fetched together, so the 6 unconditional levels cost 3 dependent round
@@ -151,65 +155,59 @@ struct HeapCol {
         }
 #pragma unroll
         for (int l = 0; l < 6; l++) ci[l] = index(ph[l + 1]);
+#if GD_EXPT == 2
+        { unsigned int acc = 0; for (int l = 0; l < 7; l++) acc ^= ci[l] + (unsigned int)ph[l + 1]; if (acc == 0x12345678u) qk[0] = lk; return; }
+#endif
         // x (the old last element) climbs from the leaf hole past every moved child that is smaller.
         // The moved children are non-increasing down the path (heap invariant), so "x passes level l"
         // is the monotone predicate c[l] = ck[l] < lk and needs no serial chain:
-        //   slot ph[l] <- ck[l-1] if c[l-1]   (x went above: the child moved up stays one lower)
+        //   slot ph[l] <- ck[l-1] if c[l-1]            (x went above: the moved child stays one lower)
         //              <- x       if c[l] && !c[l-1]
-        //              <- ck[l]   otherwise   (x rests below)
+        //              <- ck[l]   otherwise            (x rests below)
+        // For the keys this is the median of (ck[l-1], ck[l], lk) since ck[l-1] >= ck[l].
         bool c[8];
 #pragma unroll
         for (int l = 0; l < 7; l++) c[l] = ck[l] < lk;
         c[7] = true;
         float nk[8];
-        unsigned short ni[8];
+        unsigned int ni[8];
+        const float inf = __builtin_inff();
 #pragma unroll
         for (int l = 0; l < 8; l++) {
-            const float here_k = l < 7 ? ck[l] : 0.f;
-            const unsigned short here_i = l < 7 ? ci[l] : (unsigned short)0;
-            nk[l] = c[l] ? lk : here_k;
-            ni[l] = c[l] ? li : here_i;
-            if (l > 0) {
-                nk[l] = c[l - 1] ? ck[l - 1] : nk[l];
-                ni[l] = c[l - 1] ? ci[l - 1] : ni[l];
-            }
+            nk[l] = __builtin_amdgcn_fmed3f(l > 0 ? ck[l - 1] : inf, l < 7 ? ck[l] : -1.f, lk);
+            ni[l] = c[l] ? li : (l < 7 ? ci[l] : 0u);
+            if (l > 0) ni[l] = c[l - 1] ? ci[l - 1] : ni[l];
         }
 #pragma unroll
-        for (int l = 0; l < 7; l++) set(ph[l], nk[l], ni[l]);
-        set(has7 ? ph[7] : ph[6], has7 ? nk[7] : nk[6], has7 ? ni[7] : ni[6]);
+        for (int l = 0; l < 7; l++) set(ph[l], nk[l], (unsigned short)ni[l]);
+        set(has7 ? ph[7] : ph[6], has7 ? nk[7] : nk[6], (unsigned short)(has7 ? ni[7] : ni[6]));
         // current values of the ancestor chain of slot K-1 (patched where the pop rewrote a slot)
-        float cur_k[7];
-        unsigned short cur_i[7];
-        cur_k[0] = nk[0]; cur_i[0] = ni[0];
+        qk[0] = nk[0]; qi[0] = ni[0];
 #pragma unroll
         for (int l = 1; l < 7; l++) {
             const bool rewritten = ph[l] == Q[l];  // ph[l] lives on level l, like Q[l]
-            cur_k[l] = rewritten ? nk[l] : qk[l];
-            cur_i[l] = rewritten ? ni[l] : qi[l];
+            qk[l] = rewritten ? nk[l] : qk[l];
+            qi[l] = rewritten ? ni[l] : qi[l];
         }
         // y climbs from slot K-1 along the chain; the chain is non-increasing towards the leaf, so
-        // p[u] = cur_k[u] < yk is monotone as well: chain position u (7 = slot K-1) receives
-        // cur[u-1] if p[u-1], y if p[u] && !p[u-1], and keeps its value otherwise.
+        // p[u] = qk[u] < yk is monotone as well: chain position u (7 = slot K-1) receives
+        // q[u-1] if p[u-1], y if p[u] && !p[u-1], and keeps its value otherwise (median again).
         bool p[8];
 #pragma unroll
-        for (int u = 0; u < 7; u++) p[u] = cur_k[u] < yk;
+        for (int u = 0; u < 7; u++) p[u] = qk[u] < yk;
         p[7] = true;
-        float out0 = 0.f;
+        float ok[8];
+        unsigned int oi[8];
 #pragma unroll
-        for (int u = 7; u >= 0; u--) {
-            const int slot = u == 7 ? K - 1 : Q[u];
-            float ok = u < 7 ? cur_k[u] : 0.f;
-            unsigned short oi = u < 7 ? cur_i[u] : (unsigned short)0;
-            ok = p[u] ? yk : ok;
-            oi = p[u] ? yi : oi;
-            if (u > 0) {
-                ok = p[u - 1] ? cur_k[u - 1] : ok;
-                oi = p[u - 1] ? cur_i[u - 1] : oi;
-            }
-            set(slot, ok, oi);
-            if (u == 0) out0 = ok;
+        for (int u = 0; u < 8; u++) {
+            ok[u] = __builtin_amdgcn_fmed3f(u > 0 ? qk[u - 1] : inf, u < 7 ? qk[u] : -1.f, yk);
+            oi[u] = p[u] ? yi : (u < 7 ? qi[u] : 0u);
+            if (u > 0) oi[u] = p[u - 1] ? qi[u - 1] : oi[u];
         }
-        return out0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) set(u == 7 ? K - 1 : Q[u], ok[u], (unsigned short)oi[u]);
+#pragma unroll
+        for (int u = 0; u < 7; u++) { qk[u] = ok[u]; qi[u] = oi[u]; }
     }
     // radiusFilter, src/knn.hpp:83-97 (swap-remove in heap-array order); returns newBeyond
     __device__ __forceinline__ int radius_filter(int len, float radius) const {
@@ -306,14 +304,28 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
             return part;
         };
 
+#if GD_EXPT == 9
+        unsigned long long x_drain = 0, x_rounds = 0, x_heavy = 0;
+        const unsigned long long t_all0 = wall_clock64();
+#endif
+        // the (x, y) stream runs two chunks ahead of the scan in registers (lanes 0..31 carry a chunk)
+        const float2 *rxy = d.road_xy + r0;
+        auto load_chunk = [&](int base) -> float2 {
+            return (lane < C && base + lane < R) ? rxy[base + lane] : make_float2(0.f, 0.f);
+        };
+        float2 pre1 = load_chunk(0), pre2 = load_chunk(C);
         for (int win = 0; win < R; win += WW * C) {
             const int win_end = min(R, win + WW * C);
             float thr = (live && win >= K) ? heap.key(0) : -1.f;
+            unsigned int nz = 0;  // bit c: chunk c of this window has candidates for this agent
             // ---- SCAN: all lanes; one mask word per 32-road chunk ----
             for (int base = win, c = 0; base < win_end; base += C, c++) {
                 const int tn = min(C, R - base);
+                const float2 cur = pre1;
+                pre1 = pre2;
+                pre2 = load_chunk(base + 2 * C);
                 wave_sync();
-                if (lane < tn) tile[lane] = d.road_xy[(size_t)r0 + base + lane];
+                if (lane < C) tile[lane] = cur;
                 wave_sync();
                 if (knn) {
                     // roads with index < K go straight into the array (src/knn.hpp:112-120)
@@ -325,8 +337,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                                 const int t = sub * PL + k;
                                 if (t < direct_end) {
                                     const float2 xy = tile[t];
-                                    const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                                    heap.set(base + t, len2_2(rel.x, rel.y), (unsigned short)(base + t));
+                                    heap.set(base + t, ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y), (unsigned short)(base + t));
                                 }
                             }
                         }
@@ -346,13 +357,17 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                         for (int k = 0; k < PL; k++) {
                             const int t = sub * PL + k;
                             const float2 xy = tile[t];
-                            const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                            const bool pass = t >= direct_end && t < tn && len2_2(rel.x, rel.y) < thr;
+#if GD_EXPT && GD_EXPT != 9
+                            const bool pass = t >= direct_end && t < tn && ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y) > -thr;
+#else
+                            const bool pass = t >= direct_end && t < tn && ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y) < thr;
+#endif
                             part |= (pass ? 1u : 0u) << t;
                         }
                     }
                     const unsigned int word = agent_or(part);
                     if (sub == 0) s_mask[c * A_T + a] = word;
+                    nz |= (word != 0u ? 1u : 0u) << c;
                 } else {
                     // AllEntitiesWithRadiusFiltering: first K in index order within the radius, sim.cpp:261-279
                     unsigned int part = 0;
@@ -360,8 +375,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                     for (int k = 0; k < PL; k++) {
                         const int t = sub * PL + k;
                         const float2 xy = tile[t];
-                        const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                        const bool pass = live && t < tn && !(len_2(rel.x, rel.y) > radius);
+                        const bool pass = live && t < tn && !(sqrtf(ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y)) > radius);
                         part |= (pass ? 1u : 0u) << t;
                     }
                     const unsigned int word = agent_or(part);
@@ -379,39 +393,88 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
             if (knn && win_end > K) {
                 wave_sync();
                 if (live && sub == 0 && !(d.debug_flags & 2)) {
-                    const int nwords = (win_end - win + C - 1) / C;
-                    int c = 0;
-                    unsigned int word = s_mask[a];
-                    // cursor over the candidate bits; the next candidate's (x, y) is fetched from L2
-                    // while the current one is replayed
+                    // cursor over the candidate bits: `nz` names the non-empty words, so a lane never
+                    // spins over empty ones, and the word after the current one is already in flight;
+                    // the next candidate's (x, y) is fetched from L2 while the current one is replayed
+                    unsigned int word = 0, wnx = 0;
+                    int c = 0, cn = 0;
+                    auto fetch = [&]() {
+                        wnx = 0;
+                        if (nz) {
+                            cn = __ffs(nz) - 1;
+                            nz &= nz - 1;
+                            wnx = s_mask[cn * A_T + a];
+                        }
+                    };
+                    fetch();
                     auto next = [&](int &r) -> bool {
-                        while (word == 0 && ++c < nwords) word = s_mask[c * A_T + a];
+                        if (word == 0) {
+                            word = wnx;
+                            c = cn;
+                            fetch();
+                        }
                         if (word == 0) return false;
                         const int b = __ffs(word) - 1;
                         word &= word - 1;
                         r = win + c * C + b;
                         return true;
                     };
-                    const float2 *rxy = d.road_xy + r0;
                     int r_cur = 0, r_nxt = 0;
                     bool has = next(r_cur);
                     float2 xy_cur = make_float2(0.f, 0.f);
                     if (has) xy_cur = rxy[r_cur];
-                    float top = heap.key(0);  // register copy of the K-th distance
+                    float qk[7];  // ancestor chain of slot K-1 incl. the root: qk[0] is the K-th distance
+                    unsigned int qi[7];
+                    heap.load_chain(qk, qi);
+#if GD_EXPT == 9
+                    if (w == 0 && a == 5) {
+                        int pc = 0;
+                        for (int cc = 0; cc < WW; cc++) pc += __popc(s_mask[cc * A_T + a]);
+                        printf("XW win %d cand %d thr %g top %g\n", win, pc, thr, qk[0]);
+                    }
+#endif
+#if GD_EXPT == 9
+                    const unsigned long long t_d0 = wall_clock64();
+#endif
                     while (has) {
+#if GD_EXPT == 9
+                        x_rounds++;
+                        x_heavy += __ballot(ego_dist2(ex, ey, inv.w, inv.z, xy_cur.x, xy_cur.y) < qk[0]) ? 1 : 0;
+#endif
                         const bool has_n = next(r_nxt);
                         float2 xy_nxt = xy_cur;
                         if (has_n) xy_nxt = rxy[r_nxt];
-                        const V2 rel = ego_relative(ex, ey, inv, xy_cur.x, xy_cur.y);
-                        const float key = len2_2(rel.x, rel.y);
-                        if (key < top) top = heap.replace_top(key, (unsigned short)r_cur);
+                        const float key = ego_dist2(ex, ey, inv.w, inv.z, xy_cur.x, xy_cur.y);
+#if GD_EXPT == 1
+                        if (key < -1.f) heap.replace_top(key, (unsigned int)r_cur, qk, qi);
+#elif GD_EXPT >= 2 && GD_EXPT != 9
+                        if (key > -1.f) heap.replace_top(key, (unsigned int)r_cur, qk, qi);
+#else
+                        if (key < qk[0]) heap.replace_top(key, (unsigned int)r_cur, qk, qi);
+#endif
                         r_cur = r_nxt;
                         xy_cur = xy_nxt;
                         has = has_n;
                     }
+#if GD_EXPT == 9
+                    x_drain += wall_clock64() - t_d0;
+#endif
                 }
             }
         }
+#if GD_EXPT == 9
+        {
+            unsigned long long mr = x_rounds, md = x_drain, mh = x_heavy;
+            for (int o = 1; o < 64; o <<= 1) {
+                mr = max(mr, (unsigned long long)__shfl_xor((long long)mr, o));
+                md = max(md, (unsigned long long)__shfl_xor((long long)md, o));
+                mh = max(mh, (unsigned long long)__shfl_xor((long long)mh, o));
+            }
+            if (lane == 0 && (w % 257) == 0)
+                printf("XP w %d wave %d rounds %llu heavy %llu drain_ticks %llu all_ticks %llu\n", w, wave, mr, mh, md,
+                       wall_clock64() - t_all0);
+        }
+#endif
         wave_sync();
         if (live && sub == 0) {
             if (knn) count = heap.radius_filter(min(R, K), radius);
@@ -472,9 +535,9 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         for (int t = 0; t < 32; t++) {
             const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), t));
             const float y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.y), t));
-            const V2 rel = ego_relative(ex, ey, inv, x, y);
+            const float d2 = ego_dist2(ex, ey, inv.w, inv.z, x, y);
             // radiusFilter keeps length() <= radius (src/knn.hpp:88); the linear scan skips length() > radius
-            const bool pass = knn ? (sqrtf(len2_2(rel.x, rel.y)) <= radius) : !(len_2(rel.x, rel.y) > radius);
+            const bool pass = knn ? (sqrtf(d2) <= radius) : !(sqrtf(d2) > radius);
             word |= (pass ? 1u : 0u) << t;
         }
         if (rb + 32 > R) word &= (1u << (R - rb)) - 1u;
@@ -521,8 +584,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
             float key = 0.f;
             if (in) {
                 const float2 xy = d.road_xy[(size_t)r0 + r];
-                const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                key = len2_2(rel.x, rel.y);
+                key = ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y);
             }
             const unsigned long long b = __ballot(in);
             const int pos = nin + __popcll(b & lower);
@@ -568,8 +630,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                 in = r < R && ((mask[(size_t)(r >> 5) * A_T + a] >> (r & 31)) & 1u);
                 if (!in) return 0xffffffffu;
                 const float2 xy = d.road_xy[(size_t)r0 + r];
-                const V2 rel = ego_relative(ex, ey, inv, xy.x, xy.y);
-                return __float_as_uint(len2_2(rel.x, rel.y));
+                return __float_as_uint(ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y));
             };
             unsigned int lo = 0u, hi = 0x7f800000u;
             while (lo < hi) {
