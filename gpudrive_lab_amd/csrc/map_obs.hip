@@ -28,10 +28,6 @@
 #include "engine.hpp"
 #include "gd_math.hpp"
 
-#ifndef GD_EXPT
-#define GD_EXPT 0
-#endif
-
 namespace gd {
 
 namespace {
@@ -155,9 +151,6 @@ struct HeapCol {
         }
 #pragma unroll
         for (int l = 0; l < 6; l++) ci[l] = index(ph[l + 1]);
-#if GD_EXPT == 2
-        { unsigned int acc = 0; for (int l = 0; l < 7; l++) acc ^= ci[l] + (unsigned int)ph[l + 1]; if (acc == 0x12345678u) qk[0] = lk; return; }
-#endif
         // x (the old last element) climbs from the leaf hole past every moved child that is smaller.
         // The moved children are non-increasing down the path (heap invariant), so "x passes level l"
         // is the monotone predicate c[l] = ck[l] < lk and needs no serial chain:
@@ -304,10 +297,6 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
             return part;
         };
 
-#if GD_EXPT == 9
-        unsigned long long x_drain = 0, x_rounds = 0, x_heavy = 0;
-        const unsigned long long t_all0 = wall_clock64();
-#endif
         // the (x, y) stream runs two chunks ahead of the scan in registers (lanes 0..31 carry a chunk)
         const float2 *rxy = d.road_xy + r0;
         auto load_chunk = [&](int base) -> float2 {
@@ -357,11 +346,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                         for (int k = 0; k < PL; k++) {
                             const int t = sub * PL + k;
                             const float2 xy = tile[t];
-#if GD_EXPT && GD_EXPT != 9
-                            const bool pass = t >= direct_end && t < tn && ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y) > -thr;
-#else
                             const bool pass = t >= direct_end && t < tn && ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y) < thr;
-#endif
                             part |= (pass ? 1u : 0u) << t;
                         }
                     }
@@ -426,55 +411,19 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                     float qk[7];  // ancestor chain of slot K-1 incl. the root: qk[0] is the K-th distance
                     unsigned int qi[7];
                     heap.load_chain(qk, qi);
-#if GD_EXPT == 9
-                    if (w == 0 && a == 5) {
-                        int pc = 0;
-                        for (int cc = 0; cc < WW; cc++) pc += __popc(s_mask[cc * A_T + a]);
-                        printf("XW win %d cand %d thr %g top %g\n", win, pc, thr, qk[0]);
-                    }
-#endif
-#if GD_EXPT == 9
-                    const unsigned long long t_d0 = wall_clock64();
-#endif
                     while (has) {
-#if GD_EXPT == 9
-                        x_rounds++;
-                        x_heavy += __ballot(ego_dist2(ex, ey, inv.w, inv.z, xy_cur.x, xy_cur.y) < qk[0]) ? 1 : 0;
-#endif
                         const bool has_n = next(r_nxt);
                         float2 xy_nxt = xy_cur;
                         if (has_n) xy_nxt = rxy[r_nxt];
                         const float key = ego_dist2(ex, ey, inv.w, inv.z, xy_cur.x, xy_cur.y);
-#if GD_EXPT == 1
-                        if (key < -1.f) heap.replace_top(key, (unsigned int)r_cur, qk, qi);
-#elif GD_EXPT >= 2 && GD_EXPT != 9
-                        if (key > -1.f) heap.replace_top(key, (unsigned int)r_cur, qk, qi);
-#else
                         if (key < qk[0]) heap.replace_top(key, (unsigned int)r_cur, qk, qi);
-#endif
                         r_cur = r_nxt;
                         xy_cur = xy_nxt;
                         has = has_n;
                     }
-#if GD_EXPT == 9
-                    x_drain += wall_clock64() - t_d0;
-#endif
                 }
             }
         }
-#if GD_EXPT == 9
-        {
-            unsigned long long mr = x_rounds, md = x_drain, mh = x_heavy;
-            for (int o = 1; o < 64; o <<= 1) {
-                mr = max(mr, (unsigned long long)__shfl_xor((long long)mr, o));
-                md = max(md, (unsigned long long)__shfl_xor((long long)md, o));
-                mh = max(mh, (unsigned long long)__shfl_xor((long long)mh, o));
-            }
-            if (lane == 0 && (w % 257) == 0)
-                printf("XP w %d wave %d rounds %llu heavy %llu drain_ticks %llu all_ticks %llu\n", w, wave, mr, mh, md,
-                       wall_clock64() - t_all0);
-        }
-#endif
         wave_sync();
         if (live && sub == 0) {
             if (knn) count = heap.radius_filter(min(R, K), radius);

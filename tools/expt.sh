@@ -1,5 +1,5 @@
 #!/bin/bash
-# developer tool: time experiment builds (gpudrive_lab_amd/expt_<n>.so, built with -DGD_EXPT=<n>)
+# developer tool: time alternative builds of the library (gpudrive_lab_amd/expt_<n>.so, selected through GPUDRIVE_AMD_LIB)
 for e in "$@"; do
   GPUDRIVE_AMD_LIB=$GRAFT_REPO_ROOT/gpudrive_lab_amd/expt_$e.so timeout -k 10 200 python bench.py --steps 20 --warmup 3 --roofline-steps 10 --no-cpu-baseline --workloads synthetic > gpurun_out/expt_$e.log 2>gpurun_out/expt_$e.err
   python -c "
