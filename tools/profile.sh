@@ -28,7 +28,7 @@ for C in ("FETCH_SIZE","WRITE_SIZE"):
     for f in glob.glob(out+"/pmc_%s/**/*counter_collection.csv"%C, recursive=True):
         for row in csv.DictReader(open(f)):
             k=row["Kernel_Name"]
-            key="k_map_obs" if "k_map_obs" in k else ("k_world_step" if "k_world_step" in k else None)
+            key=next((n for n in ("k_map_obs","k_world_step","k_lidar","k_bev") if n in k), None)
             if key: agg[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary={k:{c:{"mean":sum(x)/len(x),"n":len(x)} for c,x in v.items()} for k,v in agg.items()}
 json.dump(summary, open(out+"/pmc_traffic_summary.json","w"), indent=1)
