@@ -62,7 +62,8 @@ class GdHostWorld(C.Structure):
 # every symbol include/gpudrive_amd.h declares
 SYMBOLS = [
     "gd_version", "gd_last_error", "gd_default_params", "gd_tensor_shape", "gd_create", "gd_destroy",
-    "gd_step", "gd_reset", "gd_set_maps", "gd_delete_agents", "gd_tensor", "gd_pack_observations", "gd_sync",
+    "gd_step", "gd_reset", "gd_set_maps", "gd_delete_agents", "gd_tensor", "gd_pack_observations",
+    "gd_expert_actions", "gd_advance_log_playback", "gd_sync",
     "gd_set_stream",
     "gd_kernel_timing_enable", "gd_kernel_timing_read", "gd_debug_get_state", "gd_debug_set_state",
     "gd_host_world_build", "gd_host_world_free",
@@ -111,6 +112,8 @@ def lib():
     L.gd_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(GdTensorDesc)]
     L.gd_sync.argtypes = [C.c_void_p]
     L.gd_pack_observations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.gd_expert_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gd_advance_log_playback.argtypes = [C.c_void_p, C.c_int32]
     L.gd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.gd_kernel_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     L.gd_kernel_timing_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

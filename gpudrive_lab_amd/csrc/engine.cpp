@@ -676,6 +676,31 @@ int gd_pack_observations(gd_sim *s, float *out, int64_t out_bytes) {
     });
 }
 
+int gd_expert_actions(gd_sim *s, float *actions, int32_t action_cols, float *pos_xy, float *vel_xy, float *yaw,
+                      int32_t *valids) {
+    if (!s) return fail(GD_ERR_INVALID, "gd_expert_actions: null sim");
+    const int cols = s->d.p.dynamicsModel == GD_DYNAMICS_STATE ? 10 : 3;
+    if (actions && action_cols != cols)
+        return fail(GD_ERR_INVALID, "gd_expert_actions: action_cols does not match the dynamics model (10 for State, else 3)");
+    return guarded([&]() {
+        gd::launch_expert_actions(s->d, s->stream, actions, pos_xy, vel_xy, yaw, valids);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int gd_advance_log_playback(gd_sim *s, int32_t init_steps) {
+    if (!s) return fail(GD_ERR_INVALID, "gd_advance_log_playback: null sim");
+    if (init_steps < 0 || init_steps >= GD_EPISODE_LEN)
+        return fail(GD_ERR_INVALID, "gd_advance_log_playback: the expert trajectory has 91 steps, init_steps must be < 91");
+    return guarded([&]() {
+        for (int t = 0; t < init_steps; t++) {
+            gd::launch_set_log_actions(s->d, s->stream, t);
+            HIP_CHECK(hipGetLastError());
+            s->step();
+        }
+    });
+}
+
 int gd_sync(gd_sim *s) {
     if (!s) return fail(GD_ERR_INVALID, "gd_sync: null sim");
     return guarded([&]() { HIP_CHECK(hipStreamSynchronize(s->stream)); });

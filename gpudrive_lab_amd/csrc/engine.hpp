@@ -62,5 +62,7 @@ void launch_map_obs(const DevSim &d, hipStream_t st);  // map_obs.hip
 void launch_bev(const DevSim &d, hipStream_t st);      // bev_lidar.hip
 void launch_lidar(const DevSim &d, hipStream_t st);    // bev_lidar.hip
 void launch_pack_obs(const DevSim &d, hipStream_t st, float *out);  // pack_obs.hip
+void launch_expert_actions(const DevSim &d, hipStream_t st, float *actions, float *pos, float *vel, float *yaw, int *valid);
+void launch_set_log_actions(const DevSim &d, hipStream_t st, int t);
 
 }  // namespace gd

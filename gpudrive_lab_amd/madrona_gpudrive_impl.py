@@ -294,6 +294,27 @@ class SimManager:
         _capi.check(self._L.gd_pack_observations(self._h, out.data_ptr(), out.numel() * 4), "gd_pack_observations")
         return out
 
+    def expert_actions(self):
+        """Extension: what `GPUDriveTorchEnv.get_expert_actions()` returns (reference
+        gpudrive/env/env_torch.py:1445-1509), from one kernel over the expert trajectory rows:
+        (inferred_actions [W,A,91,3 or 10], pos_xy [W,A,91,2], vel_xy [W,A,91,2], yaw [W,A,91,1],
+        valids [W,A,91,1] int32), inferred actions clamped per dynamics model."""
+        import torch
+        cols = 10 if int(self._params.dynamicsModel) == int(DynamicsModel.State) else 3
+        mk = lambda c, dt=torch.float32: torch.empty((self._W, self._A, episodeLen, c), dtype=dt, device=self._device)
+        act, pos, vel, yaw, valid = mk(cols), mk(2), mk(2), mk(1), mk(1, torch.int32)
+        self._bind_stream()
+        _capi.check(self._L.gd_expert_actions(self._h, act.data_ptr(), cols, pos.data_ptr(), vel.data_ptr(), yaw.data_ptr(),
+                                              valid.data_ptr()), "gd_expert_actions")
+        return act, pos, vel, yaw, valid
+
+    def advance_log_playback(self, init_steps):
+        """Extension: `GPUDriveTorchEnv.advance_sim_with_log_playback(init_steps)` (reference
+        gpudrive/env/env_torch.py:1274-1293) without leaving the device: every step feeds the logged
+        (inferred) action of that time step to every agent slot and steps.  ValueError if init_steps >= 91."""
+        self._bind_stream()
+        _capi.check(self._L.gd_advance_log_playback(self._h, int(init_steps)), "gd_advance_log_playback")
+
     # ---- dead / out-of-scope API kept for attribute compatibility ----
     def bev_observation_tensor(self):
         """[W, A, 200, 200, 1] f32.  The reference always rasterises the BEV (160 KB per agent, 10.5 GB

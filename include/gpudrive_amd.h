@@ -155,6 +155,18 @@ int gd_tensor(gd_sim *sim, int32_t id, gd_tensor_desc *out);
  * out[W][A][6 + (A-1)*6 + 200*13] f32 = ego | partners | road points (type one-hot over 7).
  * `out` is a device pointer of at least out_bytes bytes. */
 int gd_pack_observations(gd_sim *sim, float *out, int64_t out_bytes);
+/* Expert-action export: GPUDriveTorchEnv.get_expert_actions()
+ * (gpudrive/env/env_torch.py:1445-1509 over gpudrive/datatypes/trajectory.py:24-41) in one pass over the
+ * expert trajectory rows.  Device pointers, any of them may be NULL:
+ *   actions f32 [W][A][91][cols]  cols = 10 for DynamicsModel::State, else 3 (clamped per model)
+ *   pos_xy  f32 [W][A][91][2], vel_xy f32 [W][A][91][2], yaw f32 [W][A][91][1], valids i32 [W][A][91][1]
+ * `action_cols` must match the simulator's dynamics model (GD_ERR_INVALID otherwise). */
+int gd_expert_actions(gd_sim *sim, float *actions, int32_t action_cols, float *pos_xy, float *vel_xy, float *yaw,
+                      int32_t *valids);
+/* GPUDriveTorchEnv.advance_sim_with_log_playback(init_steps) (gpudrive/env/env_torch.py:1274-1293): for
+ * t = 0 .. init_steps-1 write the expert action of step t into action[:, :, :cols] of every agent slot
+ * (env_torch.py:645-664) and step.  init_steps >= 91 is GD_ERR_INVALID (the reference raises ValueError). */
+int gd_advance_log_playback(gd_sim *sim, int32_t init_steps);
 /* Block until everything launched so far has finished (the reference's step() is synchronous). */
 int gd_sync(gd_sim *sim);
 /* Change the launch stream (e.g. torch's current stream). */

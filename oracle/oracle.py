@@ -101,6 +101,34 @@ def lib(path=None):
     return L
 
 
+def expert_actions_of(raw, dynamics_model):
+    """GPUDriveTorchEnv.get_expert_actions() (reference gpudrive/env/env_torch.py:1445-1509) over
+    LogTrajectory's slicing of the trajectory rows (gpudrive/datatypes/trajectory.py:24-41).
+    raw: [W, A, 1456] float32; dynamics_model: 0 classic, 1 bicycle, 2 delta_local, 3 state.
+    torch.clamp with Python scalars on a float32 tensor clamps against the float32 bounds."""
+    T = 91
+    W, A = raw.shape[:2]
+    pos = raw[:, :, :2 * T].reshape(W, A, T, 2)
+    vel = raw[:, :, 2 * T:4 * T].reshape(W, A, T, 2)
+    yaw = raw[:, :, 4 * T:5 * T].reshape(W, A, T, 1)
+    with np.errstate(invalid="ignore"):
+        valids = raw[:, :, 5 * T:6 * T].reshape(W, A, T, 1).astype(np.int32)
+    inferred = raw[:, :, 6 * T:16 * T].reshape(W, A, T, 10)
+    f32 = np.float32
+    if dynamics_model == 3:    # state: (x, y, 1, yaw, vx, vy, 0, 0, 0, 0), :1470-1487
+        act = np.concatenate([pos, np.ones((W, A, T, 1), f32), yaw, vel, np.zeros((W, A, T, 4), f32)], -1)
+    elif dynamics_model == 2:  # delta_local, :1460-1469
+        act = inferred[..., :3].copy()
+        act[..., 0] = np.clip(act[..., 0], f32(-6), f32(6))
+        act[..., 1] = np.clip(act[..., 1], f32(-6), f32(6))
+        act[..., 2] = np.clip(act[..., 2], f32(-np.pi), f32(np.pi))
+    else:                      # classic / bicycle, :1488-1499
+        act = inferred[..., :3].copy()
+        act[..., 0] = np.clip(act[..., 0], f32(-6), f32(6))
+        act[..., 1] = np.clip(act[..., 1], f32(-0.3), f32(0.3))
+    return act.astype(f32), pos.copy(), vel.copy(), yaw.copy(), valids
+
+
 def default_params(**kw):
     """Defaults of src/init.hpp:111-127 (polylineReductionThreshold / observationRadius /
     rewardParams have no default there; zero-initialised like `Parameters()` from Python)."""
@@ -253,6 +281,21 @@ class OracleSim:
     def agent_id_tensor(self): return self._view("agent_id", (self.W, self.A), np.int32)
 
     # --- test hooks ---
+    # ---- expert-action export and log playback (callers of the path) ----
+    def expert_actions(self):
+        return expert_actions_of(np.array(self.expert_trajectory_tensor()), int(self.p.dynamicsModel))
+
+    def advance_log_playback(self, init_steps):
+        """GPUDriveTorchEnv.advance_sim_with_log_playback (env_torch.py:1274-1293): step t copies
+        log_playback_traj[:, :, t, :] into action[:, :, :cols] (env_torch.py:645-664) and steps."""
+        if init_steps >= 91:
+            raise ValueError("The length of the expert trajectory is 91, so init_steps should be < 91.")
+        act = self.expert_actions()[0]
+        cols = act.shape[-1]
+        for t in range(init_steps):
+            self.action_tensor()[:, :, :cols] = act[:, :, t, :]
+            self.step()
+
     def knn_inserts(self):
         return int(self.L.orc_knn_inserts(self.h))
 
