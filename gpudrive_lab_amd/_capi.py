@@ -66,7 +66,7 @@ SYMBOLS = [
     "gd_expert_actions", "gd_advance_log_playback", "gd_sync",
     "gd_set_stream",
     "gd_kernel_timing_enable", "gd_kernel_timing_read", "gd_debug_get_state", "gd_debug_set_state",
-    "gd_host_world_build", "gd_host_world_free",
+    "gd_host_world_build", "gd_host_world_free", "gd_scene_cache_write",
 ]
 
 
@@ -112,6 +112,7 @@ def lib():
     L.gd_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(GdTensorDesc)]
     L.gd_sync.argtypes = [C.c_void_p]
     L.gd_pack_observations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.gd_scene_cache_write.argtypes = [C.c_char_p, C.c_float, C.c_char_p]
     L.gd_expert_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gd_advance_log_playback.argtypes = [C.c_void_p, C.c_int32]
     L.gd_set_stream.argtypes = [C.c_void_p, C.c_void_p]

@@ -308,7 +308,7 @@ struct gd_sim {
             } else {
                 auto sit = scene_cache.find(path);
                 if (sit == scene_cache.end())
-                    sit = scene_cache.emplace(path, gd::parse_scene_file(path, params.polylineReductionThreshold)).first;
+                    sit = scene_cache.emplace(path, gd::load_scene(path, params.polylineReductionThreshold)).first;
                 hw = std::make_shared<gd::HostWorld>();
                 gd::build_host_world(*sit->second, params, A, del, ndel, *hw);
                 world_cache.emplace(key, hw);
@@ -784,7 +784,7 @@ int gd_host_world_build(const char *scene, const gd_params *params, int32_t A, c
     if (!scene || !params || !out || A < 2 || A > GD_MAX_AGENTS_LIMIT) return fail(GD_ERR_INVALID, "gd_host_world_build: bad argument");
     std::memset(out, 0, sizeof(*out));
     return guarded([&]() {
-        auto map = gd::parse_scene_file(scene, params->polylineReductionThreshold);
+        auto map = gd::load_scene(scene, params->polylineReductionThreshold);
         gd::HostWorld hw;
         gd::build_host_world(*map, *params, A, deleted, ndel, hw);
         out->num_agents = hw.num_agents;
@@ -814,6 +814,15 @@ int gd_host_world_build(const char *scene, const gd_params *params, int32_t A, c
         out->agent_id = dupi(hw.agent_id);
         out->entity_type = dupi(hw.etype);
         out->metadata = dupi(hw.metadata);
+    });
+}
+
+int gd_scene_cache_write(const char *scene, float polyline_reduction_threshold, const char *out_path) {
+    if (!scene || !out_path) return fail(GD_ERR_INVALID, "gd_scene_cache_write: null argument");
+    if (!gd::is_scene_cache_path(out_path)) return fail(GD_ERR_INVALID, "gd_scene_cache_write: the cache path must end in .gdsm");
+    return guarded([&]() {
+        auto map = gd::load_scene(scene, polyline_reduction_threshold);
+        gd::write_scene_cache(*map, polyline_reduction_threshold, out_path);
     });
 }
 

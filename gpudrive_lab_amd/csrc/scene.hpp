@@ -54,6 +54,14 @@ struct SceneMap {
 // Throws std::runtime_error (parse) / std::invalid_argument with "cannot open" (io).
 std::shared_ptr<const SceneMap> parse_scene_file(const std::string &path, float polyline_reduction_threshold);
 
+// Binary scene cache (scene_cache.cpp): a ".gdsm" file is the parsed, polyline-reduced SceneMap.
+bool is_scene_cache_path(const std::string &path);
+void write_scene_cache(const SceneMap &map, float polyline_reduction_threshold, const std::string &out_path);
+// Throws std::invalid_argument when the cache was built with another threshold.
+std::shared_ptr<const SceneMap> read_scene_cache(const std::string &path, float polyline_reduction_threshold);
+// parse_scene_file or read_scene_cache, by extension: every scene path of the API goes through here.
+std::shared_ptr<const SceneMap> load_scene(const std::string &path, float polyline_reduction_threshold);
+
 // One collidable road box (RoadEdge / StopSign ...), precomputed on the host.
 struct RoadBox {
     float cx, cy, radius, type;  // centre, bounding-circle radius, EntityType as float

@@ -200,6 +200,13 @@ int gd_host_world_build(const char *scene, const gd_params *params, int32_t max_
                         const int32_t *deleted_ids, int32_t n_deleted, gd_host_world *out);
 void gd_host_world_free(gd_host_world *w);
 
+/* Binary scene cache: parse `scene` (JSON) once the way MapReader::parseAndWriteOut +
+ * from_json(Map) do (src/MapReader.cpp:46-61, src/json_serialization.hpp) and write the parsed, polyline-reduced
+ * map to `out_path`, which must end in ".gdsm".  A ".gdsm" path is accepted wherever a scene path is (gd_create,
+ * gd_set_maps, gd_host_world_build) and loads ~100x faster than the JSON; the worlds built from it are bit-identical.
+ * The threshold is stored: asking for another one later is GD_ERR_INVALID.  Host only, no device needed. */
+int gd_scene_cache_write(const char *scene, float polyline_reduction_threshold, const char *out_path);
+
 #ifdef __cplusplus
 }
 #endif

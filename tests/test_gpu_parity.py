@@ -277,6 +277,32 @@ def test_log_playback_matches_oracle(oracle_mod, model):
     gpu.close()
 
 
+def test_scene_cache_gives_identical_simulator(tmp_path):
+    """a simulator built (and re-mapped with set_maps) from .gdsm caches holds the same
+    bytes in every exported tensor as one built from the JSON scenes."""
+    from gpudrive_lab_amd import scene_cache
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, **ALL_OBJECTS)
+    scenes = [SCENE_4, SCENE_407, TEST_JSON, SCENE_4]
+    cached = scene_cache.build_cache(scenes, 0.1, out_dir=str(tmp_path))
+    a = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    b = P.make_gpu_sim(cached, max_agents=64, **kw)
+    import torch
+    names = list(P.INT_TENSORS) + list(P.OBS_TENSORS) + list(P.STATIC_FLOAT_TENSORS)
+
+    def same():
+        for n in names:
+            x, y = getattr(a, n)().to_torch(), getattr(b, n)().to_torch()
+            assert x.shape == y.shape and torch.equal(x.reshape(-1).view(torch.int32), y.reshape(-1).view(torch.int32)), n
+    same()
+    for sim in (a, b):
+        sim.step()
+    same()
+    a.set_maps(scenes[::-1])
+    b.set_maps(cached[::-1])
+    same()
+    a.close(); b.close()
+
+
 EDGE_SCENES = [
     # (name, n_agents, n_polylines, pts_per_polyline)  ->  road entities = n_polylines * (pts - 1)
     ("roads_below_K", 5, 3, 51),         # R = 150 < K: no heap, radius filter + zero fill only

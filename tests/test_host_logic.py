@@ -143,3 +143,63 @@ def test_host_world_deleted_agents(L, oracle_mod):
     assert np.array_equal(hw["agent_id"], sim.agent_id_tensor()[0])
     assert np.array_equal(hw["controlled"], sim.controlled_state_tensor()[0, :, 0])
     assert np.array_equal(hw["trajectory"].view(np.uint32), sim.expert_trajectory_tensor()[0].view(np.uint32))
+
+
+# ---- binary scene cache ----
+@pytest.mark.parametrize("scene,A,kw", CASES)
+def test_scene_cache_worlds_are_bit_identical(L, tmp_path, scene, A, kw):
+    """A world built from the .gdsm cache equals the world built from the JSON, byte for byte, for every
+    parameter combination above and with deleted agents (deleteAgents re-builds from the same map)."""
+    from gpudrive_lab_amd import scene_cache
+    (cached,) = scene_cache.build_cache([scene], kw["polylineReductionThreshold"], out_dir=str(tmp_path))
+    assert cached.endswith(".gdsm") and os.path.getsize(cached) < os.path.getsize(scene)
+    for deleted in ((), (3, 7)):
+        a = _host_world(L, scene, A, deleted=deleted, **kw)
+        b = _host_world(L, cached, A, deleted=deleted, **kw)
+        for k in a:
+            x, y = np.asarray(a[k]), np.asarray(b[k])
+            assert x.shape == y.shape and x.tobytes() == y.tobytes(), k
+
+
+def test_scene_cache_guards(L, tmp_path):
+    from gpudrive_lab_amd import scene_cache
+    (cached,) = scene_cache.build_cache([SCENE_4], 0.1, out_dir=str(tmp_path))
+    p = _capi.GdParams()
+    L.gd_default_params(C.byref(p))
+    hw = _capi.GdHostWorld()
+    p.polylineReductionThreshold = 0.5  # another threshold than the one baked into the file
+    assert L.gd_host_world_build(cached.encode(), C.byref(p), 64, None, 0, C.byref(hw)) == _capi.GD_ERR_INVALID
+    assert b"polylineReductionThreshold" in L.gd_last_error()
+    p.polylineReductionThreshold = 0.1
+    blob = open(cached, "rb").read()
+    trunc = str(tmp_path / "trunc.gdsm")
+    open(trunc, "wb").write(blob[:len(blob) // 2])
+    assert L.gd_host_world_build(trunc.encode(), C.byref(p), 64, None, 0, C.byref(hw)) == _capi.GD_ERR_PARSE
+    junk = str(tmp_path / "junk.gdsm")
+    open(junk, "wb").write(b"\0" * 4096)
+    assert L.gd_host_world_build(junk.encode(), C.byref(p), 64, None, 0, C.byref(hw)) == _capi.GD_ERR_PARSE
+    assert L.gd_host_world_build(str(tmp_path / "missing.gdsm").encode(), C.byref(p), 64, None, 0, C.byref(hw)) == _capi.GD_ERR_IO
+    assert L.gd_scene_cache_write(SCENE_4.encode(), 0.1, str(tmp_path / "x.bin").encode()) == _capi.GD_ERR_INVALID
+    # a cache can be re-written from a cache, and build_cache reuses fresh files
+    again = str(tmp_path / "again.gdsm")
+    assert L.gd_scene_cache_write(cached.encode(), 0.1, again.encode()) == 0
+    assert open(again, "rb").read() == blob
+    t0 = os.path.getmtime(cached)
+    assert scene_cache.build_cache([SCENE_4, SCENE_4], 0.1, out_dir=str(tmp_path)) == [cached, cached]
+    assert os.path.getmtime(cached) == t0
+
+
+def test_scene_cache_is_much_faster_than_json(L, tmp_path):
+    import time
+    from gpudrive_lab_amd import scene_cache
+    (cached,) = scene_cache.build_cache([SCENE_4], 0.1, out_dir=str(tmp_path))
+    def best(path):
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            _host_world(L, path, 64, polylineReductionThreshold=0.1)
+            ts.append(time.perf_counter() - t)
+        return min(ts)
+    tj, tc = best(SCENE_4), best(cached)
+    print("host world build: json %.2f ms, cache %.2f ms" % (tj * 1e3, tc * 1e3))
+    assert tc < tj / 2
