@@ -59,11 +59,27 @@ class GdHostWorld(C.Structure):
                 ("vehicle_size", C.POINTER(C.c_float)), ("goal", C.POINTER(C.c_float))]
 
 
+EPISODE_STATS = 12
+EPISODE_STAT_NAMES = ("episodes", "finished_agents", "return_sum", "off_road_agents", "collided_agents", "goal_achieved",
+                      "truncated_agents", "length_sum", "total_collisions", "total_off_road")
+
+
+class GdEpisodeConfig(C.Structure):
+    _fields_ = [("collision_weight", C.c_float), ("goal_achieved_weight", C.c_float), ("off_road_weight", C.c_float),
+                ("reward_type", C.c_int32), ("auto_reset", C.c_int32)]
+
+
+class GdEpisodeBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "controlled_mask", "agent_episode_returns", "episode_lengths", "collided_in_episode", "offroad_in_episode",
+        "live_agent_mask", "reward_out", "terminal_out", "truncated_out", "mask_out", "done_worlds", "stats", "world_stats")]
+
+
 # every symbol include/gpudrive_amd.h declares
 SYMBOLS = [
     "gd_version", "gd_last_error", "gd_default_params", "gd_tensor_shape", "gd_create", "gd_destroy",
     "gd_step", "gd_reset", "gd_set_maps", "gd_delete_agents", "gd_tensor", "gd_pack_observations",
-    "gd_expert_actions", "gd_advance_log_playback", "gd_sync",
+    "gd_expert_actions", "gd_advance_log_playback", "gd_episode_step", "gd_sync",
     "gd_set_stream",
     "gd_kernel_timing_enable", "gd_kernel_timing_read", "gd_debug_get_state", "gd_debug_set_state",
     "gd_host_world_build", "gd_host_world_free", "gd_scene_cache_write",
@@ -112,6 +128,7 @@ def lib():
     L.gd_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(GdTensorDesc)]
     L.gd_sync.argtypes = [C.c_void_p]
     L.gd_pack_observations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.gd_episode_step.argtypes = [C.c_void_p, C.POINTER(GdEpisodeConfig), C.POINTER(GdEpisodeBuffers)]
     L.gd_scene_cache_write.argtypes = [C.c_char_p, C.c_float, C.c_char_p]
     L.gd_expert_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gd_advance_log_playback.argtypes = [C.c_void_p, C.c_int32]

@@ -47,6 +47,7 @@ __device__ __forceinline__ BevEnt bev_entity(float cx, float cy, float yaw, floa
 template <int A_T>
 __global__ __launch_bounds__(256) void k_bev(DevSim d) {
     const int a = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int n = d.shape[w * 2 + 0];
     if (a >= n) return;  // rows of padding agents are never written (src/level_gen.cpp:308-336)
     const int wave = tid >> 6, lane = tid & 63;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
     // (agents x worlds) tiny workgroups spent most of its time in workgroup launch/teardown.
     constexpr int NS = GD_NUM_LIDAR_SAMPLES;
     const int w = blockIdx.x, tid = threadIdx.x;
+    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int wave = tid >> 6, lane = tid & 63;
     const int n = d.shape[w * 2 + 0];
     const int r0 = d.road_off[w];

@@ -438,8 +438,26 @@ struct gd_sim {
 
     void do_reset(const std::vector<int32_t> &flags) {
         upload_flags(d.reset_flags, flags);
-        launch(gd::KERNEL_RESET, false);
-        run_rest(false);
+        reset_flagged(false);
+    }
+
+    // resetSystem + the observation half of the task graph (src/sim.cpp:150-166, 960-971) for the worlds
+    // whose reset flag is set ON THE DEVICE (by the upload above or by k_episode_step).  Like the
+    // reference's Reset graph the observation systems re-run for EVERY world (not idempotent in the
+    // reference: the collision system sees the already decremented step counter, so a reset anywhere can
+    // raise collision flags elsewhere -- reproduced, and tested).  `gated`: the host does not know whether
+    // k_episode_step flagged anything; the kernels are launched regardless and return at once unless
+    // *any_reset is set, so a step without finished worlds costs three empty launches and no host sync.
+    void reset_flagged(bool gated) {
+        d.gate_any = gated ? 1 : 0;
+        try {
+            launch(gd::KERNEL_RESET, false);
+            run_rest(false);
+        } catch (...) {
+            d.gate_any = 0;
+            throw;
+        }
+        d.gate_any = 0;
     }
 };
 
@@ -579,6 +597,8 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.resp = s->alloc_internal<int32_t>(WA);
         d.reset_flags = s->alloc_internal<int32_t>(W);
         d.rebuilt_flags = s->alloc_internal<int32_t>(W);
+        d.any_reset = s->alloc_internal<int32_t>(1);
+        d.gate_any = 0;
         d.road_off = s->alloc_internal<int32_t>(W + 1);
         d.box_off = s->alloc_internal<int32_t>(W + 1);
         d.grid = s->alloc_internal<gd::GridHdr>(W);
@@ -698,6 +718,22 @@ int gd_advance_log_playback(gd_sim *s, int32_t init_steps) {
             HIP_CHECK(hipGetLastError());
             s->step();
         }
+    });
+}
+
+int gd_episode_step(gd_sim *s, const gd_episode_config *cfg, const gd_episode_buffers *b) {
+    if (!s || !cfg || !b) return fail(GD_ERR_INVALID, "gd_episode_step: null argument");
+    if (!b->controlled_mask || !b->agent_episode_returns || !b->episode_lengths || !b->collided_in_episode ||
+        !b->offroad_in_episode || !b->live_agent_mask || !b->reward_out || !b->terminal_out || !b->truncated_out ||
+        !b->mask_out || !b->done_worlds || !b->stats || !b->world_stats)
+        return fail(GD_ERR_INVALID, "gd_episode_step: every buffer is required");
+    if (cfg->reward_type != GD_EPISODE_REWARD_WEIGHTED && cfg->reward_type != GD_EPISODE_REWARD_SPARSE)
+        return fail(GD_ERR_INVALID, "gd_episode_step: unknown reward_type");
+    return guarded([&]() {
+        HIP_CHECK(hipMemsetAsync(s->d.any_reset, 0, sizeof(int32_t), s->stream));
+        gd::launch_episode_step(s->d, s->stream, *cfg, *b);
+        HIP_CHECK(hipGetLastError());
+        if (cfg->auto_reset) s->reset_flagged(true);
     });
 }
 

@@ -44,6 +44,9 @@ struct DevSim {
     int32_t *etype, *agent_id, *resp;
     // per world flags
     int32_t *reset_flags, *rebuilt_flags;
+    int32_t *any_reset;    // one int: k_episode_step raised at least one reset flag in this step
+    int gate_any;          // reset pass launched without knowing on the host whether anything was flagged:
+                           // every workgroup returns at once unless *any_reset is set
     // roads
     const int32_t *road_off;  // [W+1]
     const float2 *road_xy;
@@ -64,5 +67,6 @@ void launch_lidar(const DevSim &d, hipStream_t st);    // bev_lidar.hip
 void launch_pack_obs(const DevSim &d, hipStream_t st, float *out);  // pack_obs.hip
 void launch_expert_actions(const DevSim &d, hipStream_t st, float *actions, float *pos, float *vel, float *yaw, int *valid);
 void launch_set_log_actions(const DevSim &d, hipStream_t st, int t);
+void launch_episode_step(const DevSim &d, hipStream_t st, const gd_episode_config &c, const gd_episode_buffers &b);  // episode.hip
 
 }  // namespace gd

@@ -183,6 +183,7 @@ constexpr int STEP_THREADS = 256;  // agents live on threads [0, A); all threads
 template <int A_T, bool MOVE>
 __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     const int w = blockIdx.x, a = threadIdx.x;
+    if (!MOVE && d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int n = d.shape[w * 2 + 0];
     const size_t i = (size_t)w * A_T + a;
     const bool live = a < n;

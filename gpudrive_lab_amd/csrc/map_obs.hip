@@ -259,6 +259,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
     constexpr int G = 64 / APW;    // lanes per agent
     static_assert(APW * NW == A_T && APW * G == 64 && C % G == 0, "geometry");
     const int w = blockIdx.x, tid = threadIdx.x;
+    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int wave = tid >> 6, lane = tid & 63;
     const int al = lane % APW, sub = lane / APW;
     const int a = wave * APW + al;
@@ -448,6 +449,7 @@ template <int A_T, int NW>
 __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
     constexpr int DW = A_T / 64;
     const int w = blockIdx.x, tid = threadIdx.x;
+    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int wave = tid >> 6, lane = tid & 63;
     const int n = d.shape[w * 2 + 0];
     const int r0 = d.road_off[w];

@@ -167,6 +167,41 @@ int gd_expert_actions(gd_sim *sim, float *actions, int32_t action_cols, float *p
  * t = 0 .. init_steps-1 write the expert action of step t into action[:, :, :cols] of every agent slot
  * (env_torch.py:645-664) and step.  init_steps >= 91 is GD_ERR_INVALID (the reference raises ValueError). */
 int gd_advance_log_playback(gd_sim *sim, int32_t init_steps);
+/* Episode bookkeeping on the device: PufferGPUDrive.step()'s tracking of live agents,
+ * episode returns / lengths / collision and off-road counts, finished worlds and their asynchronous reset
+ * (gpudrive/env/env_puffer.py:250-403; rewards gpudrive/env/env_torch.py:469-505) without a host round trip.
+ * Call after gd_step.  All pointers are device pointers owned by the caller, [W][A] unless noted. */
+enum { GD_EPISODE_REWARD_WEIGHTED = 0,  /* "weighted_combination": cw*collided + gw*goal_achieved + ow*off_road */
+       GD_EPISODE_REWARD_SPARSE = 1 };  /* "sparse_on_goal_achieved": the simulator's reward tensor */
+enum { GD_EPISODE_STAT_EPISODES = 0,    /* finished worlds */
+       GD_EPISODE_STAT_FINISHED_AGENTS, /* controlled agents in them */
+       GD_EPISODE_STAT_RETURN_SUM,      /* sum of agent_episode_returns over those agents */
+       GD_EPISODE_STAT_OFF_ROAD_AGENTS, /* agents with offroad_in_episode > 0 */
+       GD_EPISODE_STAT_COLLIDED_AGENTS, /* agents with collided_in_episode > 0 */
+       GD_EPISODE_STAT_GOAL_ACHIEVED,   /* sum of info.goal_achieved */
+       GD_EPISODE_STAT_TRUNCATED_AGENTS,
+       GD_EPISODE_STAT_LENGTH_SUM,      /* sum of episode_lengths over ALL slots of the finished worlds */
+       GD_EPISODE_STAT_TOTAL_COLLISIONS, GD_EPISODE_STAT_TOTAL_OFF_ROAD, /* sums over all slots */
+       GD_EPISODE_STATS = 12 };
+typedef struct gd_episode_config {
+    float collision_weight, goal_achieved_weight, off_road_weight;
+    int32_t reward_type;  /* GD_EPISODE_REWARD_* */
+    int32_t auto_reset;   /* raise the reset flag of finished worlds and reset them (resetSystem + observations) */
+} gd_episode_config;
+typedef struct gd_episode_buffers {
+    const uint8_t *controlled_mask;  /* cont_agent_mask captured at t = 0 (bool) */
+    /* running state, read and written */
+    float *agent_episode_returns, *episode_lengths, *collided_in_episode, *offroad_in_episode;
+    uint8_t *live_agent_mask;
+    /* per-step outputs */
+    float *reward_out;
+    uint8_t *terminal_out, *truncated_out, *mask_out;
+    int32_t *done_worlds;  /* [W] 1 for worlds whose episode ended in this step */
+    float *stats;          /* [GD_EPISODE_STATS] running sums over finished episodes (the caller zeroes them) */
+    float *world_stats;    /* [W][GD_EPISODE_STATS] the same for the last finished episode of each world */
+} gd_episode_buffers;
+int gd_episode_step(gd_sim *sim, const gd_episode_config *cfg, const gd_episode_buffers *buffers);
+
 /* Block until everything launched so far has finished (the reference's step() is synchronous). */
 int gd_sync(gd_sim *sim);
 /* Change the launch stream (e.g. torch's current stream). */
