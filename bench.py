@@ -43,14 +43,14 @@ def params_for(workload):
     kw = dict(observationRadius=50.0, collisionBehaviour=2, rewardType=1, distanceToGoalThreshold=2.0,
               dynamicsModel=0, roadObservationAlgorithm=0, isStaticAgentControlled=1,
               initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
-    kw["polylineReductionThreshold"] = 0.0 if workload == "synthetic" else 0.1
+    kw["polylineReductionThreshold"] = 0.0 if workload in ("synthetic", "rl_loop") else 0.1
     if workload == "lidar":  # BASELINE configs[4]: LiDAR 3 x 50 rays, mixed vehicle / cyclist / pedestrian agents
         kw["enableLidar"] = 1
     return kw
 
 
 def scenes_for(workload, worlds, rank):
-    if workload == "synthetic":
+    if workload in ("synthetic", "rl_loop"):
         d = os.path.join(tempfile.gettempdir(), "gpudrive_amd_bench_scenes")
         paths = synth.write_scenes(d, [rank * 1000 + i for i in range(8)])
         return [paths[i % len(paths)] for i in range(worlds)]
@@ -80,10 +80,16 @@ def action_batches(worlds, agents, device, seed, n=8):
     return out
 
 
-def run_steps(sim, batches, all_worlds, n, start=0):
+def run_steps(sim, batches, all_worlds, n, start=0, tracker=None):
     act = sim.action_tensor().to_torch()
     for k in range(start, start + n):
         act.copy_(batches[k % len(batches)])
+        if tracker is not None:
+            # "rl_loop": the step as a learner sees it: simulator step, episode
+            # bookkeeping + device-driven reset of finished worlds, fused observation pack; no host sync
+            tracker.step()
+            sim.packed_observations()
+            continue
         sim.step()
         if (k + 1) % EPISODE == 0:
             sim.reset(all_worlds)
@@ -110,12 +116,16 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
     roads = int(shape[:, 1].sum())
     batches = action_batches(args.worlds, args.agents, device, seed=1234 + rank)
     all_worlds = np.arange(args.worlds, dtype=np.int32)
+    tracker = None
+    if workload == "rl_loop":
+        from gpudrive_lab_amd.episode import EpisodeTracker
+        tracker = EpisodeTracker(sim)
 
-    k = run_steps(sim, batches, all_worlds, args.warmup)
+    k = run_steps(sim, batches, all_worlds, args.warmup, tracker=tracker)
     sharding.barrier(device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    k = run_steps(sim, batches, all_worlds, args.steps, start=k)
+    k = run_steps(sim, batches, all_worlds, args.steps, start=k, tracker=tracker)
     torch.cuda.synchronize(device)
     sharding.barrier(device)
     elapsed = time.perf_counter() - t0
@@ -130,7 +140,7 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
     # dominant-kernel roofline: HIP events on the engine's stream around every launch of the road
     # observation kernel, over a separate timed stretch (so `value` is not perturbed)
     sim.kernel_timing(True)
-    run_steps(sim, batches, all_worlds, args.roofline_steps, start=k)
+    run_steps(sim, batches, all_worlds, args.roofline_steps, start=k, tracker=tracker)
     torch.cuda.synchronize(device)
     names = {0: "k_world_step", 1: "k_map_obs"}
     if workload == "lidar":
@@ -212,7 +222,7 @@ def main():
     ap.add_argument("--worlds", type=int, default=1024, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=64, choices=(64, 128))
     ap.add_argument("--roofline-steps", type=int, default=40)
-    ap.add_argument("--workloads", default="synthetic,waymo,lidar",
+    ap.add_argument("--workloads", default="synthetic,waymo,lidar,rl_loop",
                     help="first = primary; synthetic | waymo | lidar (Waymo tiles + 360-degree LiDAR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default=None, choices=(None, "nccl", "gloo"),

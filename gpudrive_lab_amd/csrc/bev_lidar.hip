@@ -155,36 +155,57 @@ __global__ __launch_bounds__(256) void k_bev(DevSim d) {
 // Madrona's absent 3-D BVH; the geometry is restated from the collision meshes' extents exactly as
 // in oracle/gd_oracle.c (lidar_system): horizontal rays see the entities whose scaled z-range
 // contains the ray height, as 2-D boxes; a box containing the origin is not hit.
-// Entity-major: every lane takes entities, culls by range and by the angular interval the
-// entity's bounding circle subtends, runs the slab test only for the rays inside it, and keeps the
-// nearest hit per (plane, ray) with a 64-bit LDS atomicMin on (t bits, entity order).
+// One workgroup per world, one wave per agent at a time.  Entity-major: in batches of 64 every lane
+// takes one entity (agent or road), culls it by plane, by range and by the angular interval its
+// bounding circle subtends, and the wave then runs the slab tests one (entity, ray) PAIR per lane:
+// entities that subtend at most 16 rays queue their pairs in LDS (prefix sum over the lanes), wider
+// (close) ones go to a per-wave list that is traced afterwards with one lane per ray.  The nearest
+// hit per (plane, ray) is kept with a 64-bit LDS atomicMin on (t bits, entity row): ties go to the
+// lowest entity row like the oracle's scan order.
 // ------------------------------------------------------------------------------------------
+// Slab test of the ray o + t d against the box (centre c, yaw quaternion (qw, qz), half extents hx, hy) in the
+// box frame.  The oracle divides; here each axis multiplies by one reciprocal (v_rcp_f32, 1 ulp): hit
+// distances move by an ulp or two, far inside the 1e-4 test tolerance.
 __device__ __forceinline__ bool ray_box(float ox, float oy, float dx, float dy, float cx, float cy, Quat rot, float hx,
                                         float hy, float &t_out) {
-    const Quat inv = quat_inv(rot);
-    const V3 lo = quat_rotate(inv, V3{ox - cx, oy - cy, 0.f});
-    const V3 ld = quat_rotate(inv, V3{dx, dy, 0.f});
+    const V2 lo = rotate_yaw(rot.w, -rot.z, ox - cx, oy - cy);  // inverse rotation
+    const V2 ld = rotate_yaw(rot.w, -rot.z, dx, dy);
     float tmin = -INFINITY, tmax = INFINITY;
     if (ld.x == 0.f) {
         if (lo.x < -hx || lo.x > hx) return false;
     } else {
-        const float t1 = (-hx - lo.x) / ld.x, t2 = (hx - lo.x) / ld.x;
-        const float lo_t = t1 < t2 ? t1 : t2, hi_t = t1 < t2 ? t2 : t1;
-        if (lo_t > tmin) tmin = lo_t;
-        if (hi_t < tmax) tmax = hi_t;
+        const float inv = __builtin_amdgcn_rcpf(ld.x);
+        const float t1 = (-hx - lo.x) * inv, t2 = (hx - lo.x) * inv;
+        tmin = fminf(t1, t2);
+        tmax = fmaxf(t1, t2);
     }
     if (ld.y == 0.f) {
         if (lo.y < -hy || lo.y > hy) return false;
     } else {
-        const float t1 = (-hy - lo.y) / ld.y, t2 = (hy - lo.y) / ld.y;
-        const float lo_t = t1 < t2 ? t1 : t2, hi_t = t1 < t2 ? t2 : t1;
-        if (lo_t > tmin) tmin = lo_t;
-        if (hi_t < tmax) tmax = hi_t;
+        const float inv = __builtin_amdgcn_rcpf(ld.y);
+        const float t1 = (-hy - lo.y) * inv, t2 = (hy - lo.y) * inv;
+        tmin = fmaxf(tmin, fminf(t1, t2));
+        tmax = fminf(tmax, fmaxf(t1, t2));
     }
     if (!(tmax >= tmin) || !(tmin > 0.f)) return false;
     t_out = tmin;
     return true;
 }
+
+// Culling only (never the hit arithmetic): atan2 to ~1e-5 rad (Abramowitz & Stegun 4.4.49 on the octant
+// ratio) and an upper bound of asin (x + (pi/2 - 1) x^3 >= asin x on [0, 1]); the ray windows derived
+// from them carry 0.02 rad and one ray of slack on either side.
+__device__ __forceinline__ float cull_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float r = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
+    const float r2 = r * r;
+    float t = r * (0.9998660f + r2 * (-0.3302995f + r2 * (0.1801410f + r2 * (-0.0851330f + 0.0208351f * r2))));
+    t = ay > ax ? 1.57079632679f - t : t;
+    t = x < 0.f ? 3.14159265359f - t : t;
+    return y < 0.f ? -t : t;
+}
+__device__ __forceinline__ float cull_asin_upper(float x) { return x + 0.5707963268f * x * x * x; }
 
 template <int A_T>
 __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
@@ -201,10 +222,20 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
     constexpr int HEAVY_CAP = 256;
     __shared__ unsigned long long s_best[4][3 * NS];
     __shared__ int s_heavy[4][HEAVY_CAP];
+    // per 64-entity batch: the culled (entity, ray) pairs and the entities' boxes, so that the slab tests run
+    // with one pair per lane whatever the per-entity ray counts are
+#ifndef GD_LIDAR_LIGHT_MAX
+#define GD_LIDAR_LIGHT_MAX 16
+#endif
+    constexpr int LIGHT_MAX = GD_LIDAR_LIGHT_MAX;  // entities that subtend more rays go to the lane-per-ray list
+    constexpr int ITEM_CAP = 64 * LIGHT_MAX;
+    __shared__ unsigned short s_items[4][ITEM_CAP];
+    __shared__ float4 s_ent[4][64][2];  // {cx, cy, qw, qz}, {hx, hy, planes, entity row}
     __shared__ float s_x[4][NS], s_y[4][NS], s_dx[4][NS], s_dy[4][NS];
 
     const float half = d.lidar_half_angle > 0.f ? d.lidar_half_angle : kPi / 3;
     const float step = 2.f * half / (float)NS;  // angle between neighbouring rays
+    const float inv_step = 1.f / step;
     const float offs[3] = {0.5f, 0.1f, -0.1f};  // src/consts.hpp:42-44
 
     for (int a = wave; a < n; a += 4) {
@@ -258,23 +289,23 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
                 if (rz >= zlo && rz <= zhi) planes |= 1 << p;
             }
             valid = valid && planes != 0;
-            const V2 rel = ego_relative(ox, oy, inv, cx, cy);
+            const V2 rel = rotate_yaw(inv.w, inv.z, cx - ox, cy - oy);
             const float rho = len_2(rel.x, rel.y), rb = sqrtf(hx * hx + hy * hy);
             valid = valid && !(rho > 200.f + rb);
             // candidate rays: theta_idx = -half + idx*step + head_angle within phi +- alpha (+ slack), all wraps
-            const float phi = atan2f(rel.y, rel.x) - head_angle;
-            const float alpha = (rho <= rb ? kPi : asinf(fminf(1.f, rb / rho))) + 0.02f;
+            const float phi = cull_atan2(rel.y, rel.x) - head_angle;
+            const float alpha = (rho <= rb ? kPi : cull_asin_upper(fminf(1.f, rb / rho))) + 0.02f;
             int lo_w[3], hi_w[3], nrays = 0;
 #pragma unroll
             for (int kw = 0; kw < 3; kw++) {
                 const float c = phi + (kw - 1) * kPiM2;
-                lo_w[kw] = max((int)floorf((c - alpha + half) / step) - 1, 0);
-                hi_w[kw] = min((int)ceilf((c + alpha + half) / step) + 1, NS - 1);
+                lo_w[kw] = max((int)floorf((c - alpha + half) * inv_step) - 1, 0);
+                hi_w[kw] = min((int)ceilf((c + alpha + half) * inv_step) + 1, NS - 1);
                 nrays += max(hi_w[kw] - lo_w[kw] + 1, 0);
             }
             // Entities that subtend many rays (close ones) would make the whole wave loop 50 times for a
             // few lanes: they go to a per-wave list and are traced afterwards with one LANE PER RAY.
-            const bool heavy = valid && nrays > 6;
+            const bool heavy = valid && nrays > LIGHT_MAX;
             const unsigned long long hb = __ballot(heavy);
             if (heavy) {
                 const int pos = nheavy + __popcll(hb & ((1ull << lane) - 1ull));
@@ -282,19 +313,58 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
             }
             const bool overflow = heavy && nheavy + __popcll(hb & ((1ull << lane) - 1ull)) >= HEAVY_CAP;
             nheavy = min(nheavy + __popcll(hb), HEAVY_CAP);
-            if (!valid || (heavy && !overflow)) continue;
+            // light entities (<= LIGHT_MAX rays, or the overflow of the heavy list): queue their (entity, ray) pairs
+            const bool light = valid && !(heavy && !overflow);
+            s_ent[wave][lane][0] = make_float4(cx, cy, q.w, q.z);
+            s_ent[wave][lane][1] = make_float4(hx, hy, __int_as_float(planes), __int_as_float(e));
+            int mine = light ? nrays : 0;
+            if (mine > LIGHT_MAX) mine = 0;  // an overflowing heavy entity is traced right here, lane-serial (rare)
+            int off = mine;          // inclusive prefix sum over the wave
 #pragma unroll
-            for (int kw = 0; kw < 3; kw++) {
-                for (int idx = lo_w[kw]; idx <= hi_w[kw]; idx++) {
-                    float t;
-                    if (!ray_box(ox, oy, s_dx[wave][idx], s_dy[wave][idx], cx, cy, q, hx, hy, t)) continue;
-                    if (!(t <= 200.f)) continue;
-                    const unsigned long long packed = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)e;
+            for (int st = 1; st < 64; st <<= 1) {
+                const int v = __shfl_up(off, st);
+                if (lane >= st) off += v;
+            }
+            const int total = __shfl(off, 63);
+            off -= mine;
+            if (mine > 0) {
 #pragma unroll
-                    for (int p = 0; p < 3; p++)
-                        if (planes & (1 << p)) atomicMin(&best[p * NS + idx], packed);
+                for (int kw = 0; kw < 3; kw++)
+                    for (int idx = lo_w[kw]; idx <= hi_w[kw]; idx++) s_items[wave][off++] = (unsigned short)((lane << 6) | idx);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int j = lane; j < total; j += 64) {
+                const int item = s_items[wave][j];
+                const int el = item >> 6, idx = item & 63;
+                const float4 e0 = s_ent[wave][el][0], e1 = s_ent[wave][el][1];
+                float t;
+                if (!ray_box(ox, oy, s_dx[wave][idx], s_dy[wave][idx], e0.x, e0.y, quat_from_wz(e0.z, e0.w), e1.x, e1.y, t)) continue;
+                if (!(t <= 200.f)) continue;
+                const int pl = __float_as_int(e1.z);
+                const unsigned long long packed = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)__float_as_int(e1.w);
+#pragma unroll
+                for (int p = 0; p < 3; p++)
+                    if (pl & (1 << p)) atomicMin(&best[p * NS + idx], packed);
+            }
+            if (light && nrays > LIGHT_MAX) {  // heavy-list overflow: same test, this lane alone
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    for (int idx = lo_w[kw]; idx <= hi_w[kw]; idx++) {
+                        float t;
+                        if (!ray_box(ox, oy, s_dx[wave][idx], s_dy[wave][idx], cx, cy, q, hx, hy, t)) continue;
+                        if (!(t <= 200.f)) continue;
+                        const unsigned long long packed = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned int)e;
+#pragma unroll
+                        for (int p = 0; p < 3; p++)
+                            if (planes & (1 << p)) atomicMin(&best[p * NS + idx], packed);
+                    }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();

@@ -157,7 +157,7 @@ struct gd_sim {
     }
 
     void launch(int which, bool move) {
-        const bool timed = timing && which < gd::KERNEL_TIMED;
+        const bool timed = timing && which < gd::KERNEL_TIMED && !d.gate_any;  // gated reset passes are mostly empty launches
         EventPair ep{};
         if (timed) {
             if (ev_used[which] == ev_pool[which].size()) {

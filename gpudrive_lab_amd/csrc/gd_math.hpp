@@ -108,6 +108,14 @@ GD_HD V2 ego_relative(float ref_x, float ref_y, Quat ref_inv, float abs_x, float
 // a dropped term only ever adds a zero, so every finite result is identical (the sign of a zero
 // result may differ, which a squared distance cannot see).  2*A is exact, so the final
 // multiply-add is written as one fma.  `qw`, `qz` are the components of the INVERSE rotation.
+// The same reduction for the rotated vector itself: rotateVec of (vx, vy, 0) by the yaw-only quaternion
+// (qw, 0, 0, qz).  Identical to quat_rotate for every finite input except for the sign of a zero.
+GD_HD V2 rotate_yaw(float qw, float qz, float vx, float vy) {
+    const float t = qz * vy, u = qz * vx;
+    const float A = t * qw + qz * u;
+    const float B = u * qw - qz * t;
+    return V2{__builtin_fmaf(-2.f, A, vx), __builtin_fmaf(2.f, B, vy)};
+}
 GD_HD float ego_dist2(float ref_x, float ref_y, float qw, float qz, float abs_x, float abs_y) {
     const float vx = abs_x - ref_x, vy = abs_y - ref_y;
     const float t = qz * vy, u = qz * vx;
