@@ -209,8 +209,9 @@ __device__ __forceinline__ float cull_asin_upper(float x) { return x + 0.5707963
 
 template <int A_T>
 __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
-    // One workgroup per world, one wave per agent at a time (agents wave, wave+4, ...): a grid of
-    // (agents x worlds) tiny workgroups spent most of its time in workgroup launch/teardown.
+    // One workgroup per 16 agents of a world, one wave per agent at a time: a grid of (agents x worlds)
+    // one-agent workgroups spent most of its time in workgroup launch/teardown, one workgroup per world
+    // left the worlds with many agents as a long tail.
     constexpr int NS = GD_NUM_LIDAR_SAMPLES;
     const int w = blockIdx.x, tid = threadIdx.x;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
@@ -238,7 +239,10 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
     const float inv_step = 1.f / step;
     const float offs[3] = {0.5f, 0.1f, -0.1f};  // src/consts.hpp:42-44
 
-    for (int a = wave; a < n; a += 4) {
+    // blockIdx.y: a group of GROUP agents of the world (worlds with many agents get several workgroups)
+    constexpr int GROUP = 16;
+    const int a_end = min(n, (int)(blockIdx.y + 1) * GROUP);
+    for (int a = blockIdx.y * GROUP + wave; a < a_end; a += 4) {
         const size_t i = (size_t)w * A_T + a;
         const float ox = d.px[i], oy = d.py[i], oz = d.pz[i];
         const Quat rot = quat_from_wz(d.qw[i], d.qz[i]);
@@ -429,7 +433,7 @@ void launch_bev(const DevSim &d, hipStream_t st) {
 }
 
 void launch_lidar(const DevSim &d, hipStream_t st) {
-    const dim3 grid(d.W);
+    const dim3 grid(d.W, d.A / 16);
     if (d.A == 64) hipLaunchKernelGGL(k_lidar<64>, grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL(k_lidar<128>, grid, dim3(256), 0, st, d);
 }
