@@ -192,6 +192,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     __shared__ float s_len[A_T], s_wid[A_T], s_hgt[A_T], s_rad[A_T];
     __shared__ int s_etype[A_T], s_id[A_T], s_flags[A_T];  // flags: bit0 active, bit1 static
     __shared__ float s_obb[14][A_T];
+    __shared__ int s_hit[A_T];  // collision flags found by the threads sharing an agent
 
     Body b{};
     int collided = 0, done = 0, resp = RESP_Static, controlled = 0, etype = 0;
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
 
     // ---- publish per-agent geometry for the pair phases ----
     bool active = false;
+    if (a < A_T) s_hit[a] = 0;
     if (live) {
         // isInvalidExpertOrDone, src/sim.cpp:631-662; agents parked at kPaddingPosition overlap nothing
         bool invalid;
@@ -291,64 +293,82 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     __syncthreads();
 
     // ---- collisionDetectionSystem over broadphase candidates, src/sim.cpp:628-747, 792-801 ----
-    if (live && active && !(d.debug_flags & 16)) {
-        Obb me;
-        {
-            float *mf = reinterpret_cast<float *>(&me);
+    // All STEP_THREADS threads work here: P = STEP_THREADS / A threads per agent share its candidate
+    // agents and the road boxes of its broadphase cell; the flags they find are OR-ed through LDS.
+    {
+        constexpr int P = STEP_THREADS / A_T;
+        const int ag = a % A_T, part = a / A_T;
+        const int my_fl = ag < n ? s_flags[ag] : 0;
+        if ((my_fl & 1) && !(d.debug_flags & 16)) {
+            Obb me;
+            {
+                float *mf = reinterpret_cast<float *>(&me);
 #pragma unroll
-            for (int k = 0; k < 14; k++) mf[k] = s_obb[k][a];
-        }
-        const float my_rad = s_rad[a];
-        const bool me_static = resp == RESP_Static;
-        for (int j = 0; j < n; j++) {
-            if (j == a) continue;
-            const int fl = s_flags[j];
-            if (!(fl & 1)) continue;
-            if (me_static && (fl & 2)) continue;  // static-static pairs are never candidates
-            const float dx = b.px - s_px[j], dy = b.py - s_py[j];
-            const float rr = (my_rad + s_rad[j]) * 1.001f + 0.01f;
-            if (dx * dx + dy * dy > rr * rr) continue;
-            Obb ot;
-            float *of = reinterpret_cast<float *>(&ot);
+                for (int k = 0; k < 14; k++) mf[k] = s_obb[k][ag];
+            }
+            const float mx = s_px[ag], my = s_py[ag], my_rad = s_rad[ag];
+            const int my_type = s_etype[ag];
+            const bool me_static = (my_fl & 2) != 0;
+            int hit = 0;  // bit 0 collided, bits 1..3 info0..info2
+            for (int j = part; j < n; j += P) {
+                if (j == ag) continue;
+                const int fl = s_flags[j];
+                if (!(fl & 1)) continue;
+                if (me_static && (fl & 2)) continue;  // static-static pairs are never candidates
+                const float dx = mx - s_px[j], dy = my - s_py[j];
+                const float rr = (my_rad + s_rad[j]) * 1.001f + 0.01f;
+                if (dx * dx + dy * dy > rr * rr) continue;
+                Obb ot;
+                float *of = reinterpret_cast<float *>(&ot);
 #pragma unroll
-            for (int k = 0; k < 14; k++) of[k] = s_obb[k][j];
-            if (!obb_collided(me, ot)) continue;
-            const int otype = s_etype[j];
-            if (collision_pair_filtered(etype, otype)) continue;
-            collided = 1;
-            if (otype > ET_None && otype <= ET_StopSign) info0 = 1;
-            else if (otype == ET_Vehicle) info1 = 1;
-            else if (otype <= ET_Cyclist) info2 = 1;
-        }
-        if (!me_static) {
-            // road boxes of the broadphase cell under the agent's centre
-            const GridHdr gh = d.grid[w];
-            const float fx = (b.px - gh.ox) * gh.inv_cell, fy = (b.py - gh.oy) * gh.inv_cell;
-            if (gh.nx > 0 && fx >= 0.f && fy >= 0.f && fx < (float)gh.nx && fy < (float)gh.ny) {
-                const int cell = (int)fy * gh.nx + (int)fx;
-                const int c0 = d.cell_off[gh.cell_base + cell], c1 = d.cell_off[gh.cell_base + cell + 1];
-                const int bbase = d.box_off[w];
-                for (int c = c0; c < c1; c++) {
-                    const size_t r = (size_t)(bbase + d.cell_items[gh.item_base + c]);
-                    const float4 hdr = d.boxes[r * 5];
-                    const int rtype = (int)hdr.w;
-                    if (collision_pair_filtered(etype, rtype)) continue;
-                    const float dx = b.px - hdr.x, dy = b.py - hdr.y;
-                    const float rr = (my_rad + hdr.z) * 1.001f + 0.01f;
-                    if (dx * dx + dy * dy > rr * rr) continue;
-                    const float4 q1 = d.boxes[r * 5 + 1], q2 = d.boxes[r * 5 + 2], q3 = d.boxes[r * 5 + 3],
-                                 q4 = d.boxes[r * 5 + 4];
-                    const float tmp[16] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
-                                           q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
-                    Obb ro;
-                    float *of = reinterpret_cast<float *>(&ro);
+                for (int k = 0; k < 14; k++) of[k] = s_obb[k][j];
+                if (!obb_collided(me, ot)) continue;
+                const int otype = s_etype[j];
+                if (collision_pair_filtered(my_type, otype)) continue;
+                hit |= 1;
+                if (otype > ET_None && otype <= ET_StopSign) hit |= 2;
+                else if (otype == ET_Vehicle) hit |= 4;
+                else if (otype <= ET_Cyclist) hit |= 8;
+            }
+            if (!me_static) {
+                // road boxes of the broadphase cell under the agent's centre
+                const GridHdr gh = d.grid[w];
+                const float fx = (mx - gh.ox) * gh.inv_cell, fy = (my - gh.oy) * gh.inv_cell;
+                if (gh.nx > 0 && fx >= 0.f && fy >= 0.f && fx < (float)gh.nx && fy < (float)gh.ny) {
+                    const int cell = (int)fy * gh.nx + (int)fx;
+                    const int c0 = d.cell_off[gh.cell_base + cell], c1 = d.cell_off[gh.cell_base + cell + 1];
+                    const int bbase = d.box_off[w];
+                    for (int c = c0 + part; c < c1; c += P) {
+                        const size_t r = (size_t)(bbase + d.cell_items[gh.item_base + c]);
+                        const float4 hdr = d.boxes[r * 5];
+                        const int rtype = (int)hdr.w;
+                        if (collision_pair_filtered(my_type, rtype)) continue;
+                        const float dx = mx - hdr.x, dy = my - hdr.y;
+                        const float rr = (my_rad + hdr.z) * 1.001f + 0.01f;
+                        if (dx * dx + dy * dy > rr * rr) continue;
+                        const float4 q1 = d.boxes[r * 5 + 1], q2 = d.boxes[r * 5 + 2], q3 = d.boxes[r * 5 + 3],
+                                     q4 = d.boxes[r * 5 + 4];
+                        const float tmp[16] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
+                                               q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
+                        Obb ro;
+                        float *of = reinterpret_cast<float *>(&ro);
 #pragma unroll
-                    for (int k = 0; k < 14; k++) of[k] = tmp[k];
-                    if (!obb_collided(me, ro)) continue;
-                    collided = 1;
-                    if (rtype > ET_None && rtype <= ET_StopSign) info0 = 1;
+                        for (int k = 0; k < 14; k++) of[k] = tmp[k];
+                        if (!obb_collided(me, ro)) continue;
+                        hit |= 1;
+                        if (rtype > ET_None && rtype <= ET_StopSign) hit |= 2;
+                    }
                 }
             }
+            if (hit) atomicOr(&s_hit[ag], hit);
+        }
+        __syncthreads();
+        if (live && active) {
+            const int hit = s_hit[a];
+            if (hit & 1) collided = 1;
+            if (hit & 2) info0 = 1;
+            if (hit & 4) info1 = 1;
+            if (hit & 8) info2 = 1;
         }
     }
 
