@@ -99,8 +99,6 @@ struct gd_sim {
     std::vector<std::vector<int32_t>> w_cell_off, w_cell_items;
     size_t cell_cap = 0, item_cap = 0;
     void *d_cell_off = nullptr, *d_cell_items = nullptr;
-    size_t mask_cap = 0;
-    void *d_mask = nullptr;
     size_t road_cap = 0, box_cap = 0;
     void *d_road_xy = nullptr, *d_road_aux = nullptr, *d_boxes = nullptr;
     // pinned flag staging ring
@@ -126,7 +124,6 @@ struct gd_sim {
         if (d_boxes) (void)hipFree(d_boxes);
         if (d_cell_off) (void)hipFree(d_cell_off);
         if (d_cell_items) (void)hipFree(d_cell_items);
-        if (d_mask) (void)hipFree(d_mask);
         for (int i = 0; i < kRing; i++) {
             if (h_flags[i]) (void)hipHostFree(h_flags[i]);
             if (flag_ev[i]) (void)hipEventDestroy(flag_ev[i]);
@@ -358,20 +355,6 @@ struct gd_sim {
             box_off[w + 1] = box_off[w] + static_cast<int32_t>(w_boxes[w].size());
         }
         const size_t nroad = road_off[W], nbox = box_off[W];
-        {
-            int max_roads = 0;
-            for (int w = 0; w < W; w++) max_roads = std::max(max_roads, road_off[w + 1] - road_off[w]);
-            const int nch = (max_roads + 31) / 32 + 1;
-            const size_t words = static_cast<size_t>(W) * nch * A;
-            if (words > mask_cap) {
-                if (d_mask) (void)hipFree(d_mask);
-                mask_cap = words;
-                HIP_CHECK(hipMalloc(&d_mask, mask_cap * sizeof(uint32_t)));
-                HIP_CHECK(hipMemset(d_mask, 0, mask_cap * sizeof(uint32_t)));
-            }
-            d.mask_scratch = static_cast<unsigned int *>(d_mask);
-            d.mask_nch = nch;
-        }
         if (nroad > road_cap) {
             if (d_road_xy) (void)hipFree(d_road_xy);
             if (d_road_aux) (void)hipFree(d_road_aux);

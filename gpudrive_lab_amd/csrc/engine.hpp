@@ -53,8 +53,6 @@ struct DevSim {
     const float4 *road_aux;
     const int32_t *box_off;   // [W+1]
     const float4 *boxes;
-    unsigned int *mask_scratch; // [W][mask_nch][A]: candidate bits of the road-observation kernel
-    int mask_nch;               // 32-road chunks per world (max over worlds)
     const GridHdr *grid;        // [W]
     const int32_t *cell_off;    // per world nx*ny+1 entries, local offsets
     const int32_t *cell_items;  // local box indices

@@ -441,13 +441,13 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
 // Same row SET as the reference (the K nearest by (distance^2, road index), then the radius filter),
 // rows in ascending road index instead of the reference's heap-history order.  Because the radius
 // filter runs after the top-K, the result is simply "every in-radius road" whenever at most K roads
-// are in radius, and the K smallest of the in-radius roads otherwise; no heap is needed, so the
-// kernel is one streaming pass: scanner waves build in-radius bit-masks (chunk x agent words in an
-// L2-resident scratch), each agent lane compacts its set bits, and the rare agents with more than K
-// in-radius roads get an exact block-cooperative selection by bisection on the key bits.
+// are in radius, and the K smallest of the in-radius roads otherwise; no heap is needed.  Each wave
+// takes its agents one at a time with all 64 lanes on the road stream: 64 roads per iteration, ballot
+// compaction of the in-radius ones (key, road) into LDS in road order, and -- only when more than K are
+// in radius -- an exact selection by bisection on the key bits (ties at the K-th distance go to the
+// lowest road index).
 template <int A_T, int NW>
 __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
-    constexpr int DW = A_T / 64;
     const int w = blockIdx.x, tid = threadIdx.x;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int wave = tid >> 6, lane = tid & 63;
@@ -463,40 +463,6 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
     __shared__ float s_ckey[NW][CAP];
     __shared__ unsigned short s_cidx[NW][CAP];
 
-    unsigned int *mask = d.mask_scratch + (size_t)w * d.mask_nch * A_T;
-    const int nchunks = (R + 31) / 32;
-
-    // in-radius masks: wave `wave` takes tasks (chunk, agent group) round-robin; lane = agent
-    for (int task = wave; task < nchunks * DW; task += NW) {
-        const int c = task / DW, a = (task % DW) * 64 + lane;
-        const int rb = c * 32;
-        const int rl = rb + (lane & 31);
-        float2 v = make_float2(0.f, 0.f);
-        if (rl < R) v = d.road_xy[(size_t)r0 + rl];
-        float ex = 0.f, ey = 0.f;
-        Quat inv{1.f, 0.f, 0.f, 0.f};
-        const bool live = a < n;
-        if (live) {
-            const size_t i = (size_t)w * A_T + a;
-            ex = d.px[i]; ey = d.py[i];
-            inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
-        }
-        unsigned int word = 0;
-#pragma unroll
-        for (int t = 0; t < 32; t++) {
-            const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), t));
-            const float y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.y), t));
-            const float d2 = ego_dist2(ex, ey, inv.w, inv.z, x, y);
-            // radiusFilter keeps length() <= radius (src/knn.hpp:88); the linear scan skips length() > radius
-            const bool pass = knn ? (sqrtf(d2) <= radius) : !(sqrtf(d2) > radius);
-            word |= (pass ? 1u : 0u) << t;
-        }
-        if (rb + 32 > R) word &= (1u << (R - rb)) - 1u;
-        if (!live) word = 0;
-        mask[(size_t)c * A_T + a] = word;
-    }
-    __syncthreads();
-
     // selection: each wave takes its agents one at a time, all 64 lanes cooperating
     constexpr int APW = A_T / NW;
     float *ckey = s_ckey[wave];
@@ -508,36 +474,25 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         const size_t i = (size_t)w * A_T + a;
         const float ex = d.px[i], ey = d.py[i];
         const Quat inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
-        // gather the in-radius candidates (key, road) in road order.  The agent's mask words are
-        // fetched up front, 64 chunks per register (one L2 latency), and then broadcast per chunk pair
-        // with v_readlane: no dependent global load in the loop.
-        constexpr int MW = (GD_MAX_ROAD_ENTITIES / 32 + 64) / 64;  // 5 registers cover 10,000 roads
-        unsigned int mw[MW];
-#pragma unroll
-        for (int q = 0; q < MW; q++) {
-            const int c = q * 64 + lane;
-            mw[q] = c < nchunks ? mask[(size_t)c * A_T + a] : 0u;
-        }
+        // gather the in-radius candidates (key, road) in road order: lane = road, 64 consecutive roads per
+        // iteration in one coalesced load issued an iteration ahead (the world's (x, y) stream is re-read
+        // per agent from L1/L2; it reaches HBM once), ballot compaction into the wave's LDS buffer
+        auto in_radius = [&](float key) -> bool {
+            // radiusFilter keeps length() <= radius (src/knn.hpp:88); the linear scan skips length() > radius
+            return knn ? (sqrtf(key) <= radius) : !(sqrtf(key) > radius);
+        };
+        const float2 *rxy = d.road_xy + r0;
         int nin = 0;
+        float2 xy_next = lane < R ? rxy[lane] : make_float2(0.f, 0.f);
         for (int rb = 0; rb < R; rb += 64) {
-            const int c0 = rb >> 5;  // even chunk index; c0 and c0+1 live in the same register
-            unsigned int w0 = 0u, w1 = 0u;
-#pragma unroll
-            for (int q = 0; q < MW; q++) {
-                if ((c0 >> 6) == q) {  // wave-uniform
-                    w0 = (unsigned int)__builtin_amdgcn_readlane((int)mw[q], c0 & 63);
-                    w1 = (unsigned int)__builtin_amdgcn_readlane((int)mw[q], (c0 + 1) & 63);
-                }
-            }
-            if ((w0 | w1) == 0u) continue;  // wave-uniform
+            const float2 xy = xy_next;
+            const int rn = rb + 64 + lane;
+            if (rn < R) xy_next = rxy[rn];
             const int r = rb + lane;
-            const bool in = ((lane < 32 ? w0 : w1) >> (lane & 31)) & 1u;
-            float key = 0.f;
-            if (in) {
-                const float2 xy = d.road_xy[(size_t)r0 + r];
-                key = ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y);
-            }
+            const float key = ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y);
+            const bool in = r < R && in_radius(key);
             const unsigned long long b = __ballot(in);
+            if (b == 0ull) continue;  // wave-uniform
             const int pos = nin + __popcll(b & lower);
             if (in && pos < CAP) { ckey[pos] = key; cidx[pos] = (unsigned short)r; }
             nin += __popcll(b);
@@ -576,24 +531,24 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
             }
         } else {
             // more in-radius roads than the LDS candidate buffer holds: same selection, keys recomputed
-            // from the scratch masks on every bisection step
+            // from the road stream on every bisection step
             auto key_bits = [&](int r, bool &in) -> unsigned int {
-                in = r < R && ((mask[(size_t)(r >> 5) * A_T + a] >> (r & 31)) & 1u);
-                if (!in) return 0xffffffffu;
-                const float2 xy = d.road_xy[(size_t)r0 + r];
-                return __float_as_uint(ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y));
+                in = false;
+                if (r >= R) return 0xffffffffu;
+                const float2 xy = rxy[r];
+                const float key = ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y);
+                in = in_radius(key);
+                return in ? __float_as_uint(key) : 0xffffffffu;
             };
             unsigned int lo = 0u, hi = 0x7f800000u;
             while (lo < hi) {
                 const unsigned int mid = lo + (hi - lo + 1) / 2;
                 int cnt = 0;
-                for (int r = lane; r < R; r += 64) { bool in; cnt += key_bits(r, in) < mid ? 1 : 0; }
-                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+                for (int rb = 0; rb < R; rb += 64) { bool in; cnt += __popcll(__ballot(key_bits(rb + lane, in) < mid)); }
                 if (cnt < K) lo = mid; else hi = mid - 1;
             }
             int less = 0;
-            for (int r = lane; r < R; r += 64) { bool in; less += key_bits(r, in) < lo ? 1 : 0; }
-            for (int off = 32; off > 0; off >>= 1) less += __shfl_xor(less, off);
+            for (int rb = 0; rb < R; rb += 64) { bool in; less += __popcll(__ballot(key_bits(rb + lane, in) < lo)); }
             int need_ties = K - less;
             for (int rb = 0; rb < R; rb += 64) {
                 bool in;
