@@ -28,6 +28,10 @@
 #include "engine.hpp"
 #include "gd_math.hpp"
 
+#ifndef GD_MAP_OBS_NW
+#define GD_MAP_OBS_NW 4
+#endif
+
 namespace gd {
 
 namespace {
@@ -223,64 +227,73 @@ __device__ __forceinline__ void wave_sync() {
 
 // Row write-out shared by both implementations: one thread per (agent, slot); a wave writes 64
 // consecutive 36-byte rows.
-template <int A_T>
-__device__ __forceinline__ void write_rows(const DevSim &d, int w, int n, int r0, bool knn, const unsigned short *s_idx,
+// Agents a0 .. a0+na-1 of the world are columns 0 .. na-1 of `s_count`; idx_of(col, s) is the road index in slot s.
+template <int A_T, typename IdxOf>
+__device__ __forceinline__ void write_rows(const DevSim &d, int w, int a0, int na, int r0, bool knn, IdxOf idx_of,
                                            const int *s_count, int tid, int nthreads) {
-    const int rows = n * K;
-    float *out = d.agent_map + (size_t)w * A_T * K * 9;
+    const int rows = na * K;
+    float *out = d.agent_map + ((size_t)w * A_T + a0) * K * 9;
     for (int p = tid; p < rows; p += nthreads) {
-        const int ego = p / K, s = p - ego * K;
+        const int col = p / K, s = p - col * K;
         float *o = out + (size_t)p * 9;
-        if (s >= s_count[ego]) {
+        if (s >= s_count[col]) {
             // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
             // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
             const float pad = knn ? 0.f : -1.f;
             o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = (float)ET_None; o[7] = pad; o[8] = pad;
             continue;
         }
-        const size_t ei = (size_t)w * A_T + ego;
-        const int r = r0 + s_idx[s * A_T + ego];
+        const size_t ei = (size_t)w * A_T + a0 + col;
+        const int r = r0 + idx_of(col, s);
         const float2 xy = d.road_xy[r];
-        const float4 a0 = d.road_aux[(size_t)r * 2], a1 = d.road_aux[(size_t)r * 2 + 1];
+        const float4 q0 = d.road_aux[(size_t)r * 2], q1 = d.road_aux[(size_t)r * 2 + 1];
         const Quat einv = quat_inv(quat_from_wz(d.qw[ei], d.qz[ei]));
         const V2 rel = ego_relative(d.px[ei], d.py[ei], einv, xy.x, xy.y);
         o[0] = rel.x; o[1] = rel.y;
-        o[2] = a0.z; o[3] = a0.w; o[4] = a1.x;
-        o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(a0.x, a0.y)));
-        o[6] = a1.y; o[7] = a1.z; o[8] = a1.w;
+        o[2] = q0.z; o[3] = q0.w; o[4] = q1.x;
+        o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0.x, q0.y)));
+        o[6] = q1.y; o[7] = q1.z; o[8] = q1.w;
     }
 }
 
-// ---- v2: NW waves per world, G lanes per agent, windowed candidate masks ----
+// ---- reference row order: workgroups of NW waves, 16 agents per wave, 4 lanes per agent ----
+// A world is A/(16 NW) workgroups.  They sit 8 block ids apart, i.e. on the same XCD (block ids go round-robin
+// over the 8 XCDs), so a world's road stream is served by one L2.
 template <int A_T, int NW, int WW>
 __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
-    constexpr int C = 32;          // roads per chunk = one mask word
-    constexpr int APW = A_T / NW;  // agents per wave
-    constexpr int G = 64 / APW;    // lanes per agent
-    static_assert(APW * NW == A_T && APW * G == 64 && C % G == 0, "geometry");
-    const int w = blockIdx.x, tid = threadIdx.x;
+    constexpr int C = 32;         // roads per chunk = one mask word
+    constexpr int APW = 16;       // agents per wave
+    constexpr int G = 64 / APW;   // lanes per agent
+    constexpr int BA = NW * APW;  // agents (LDS heap columns) per workgroup
+    constexpr int BPW = A_T / BA; // workgroups per world
+    static_assert(BA * BPW == A_T && C % G == 0, "geometry");
+    const int tid = threadIdx.x;
+    const int w = ((int)blockIdx.x / (8 * BPW)) * 8 + ((int)blockIdx.x & 7);
+    const int a0 = (((int)blockIdx.x >> 3) % BPW) * BA;
+    if (w >= d.W) return;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int wave = tid >> 6, lane = tid & 63;
     const int al = lane % APW, sub = lane / APW;
-    const int a = wave * APW + al;
+    const int col = wave * APW + al;  // heap column of this agent
+    const int a = a0 + col;
     const int n = d.shape[w * 2 + 0];
     const int r0 = d.road_off[w];
     const int R = d.road_off[w + 1] - r0;
     const bool live = a < n;
     const size_t i = (size_t)w * A_T + a;
 
-    __shared__ float s_keys[K * A_T];
-    __shared__ unsigned short s_idx[K * A_T];
-    __shared__ unsigned int s_mask[WW * A_T];  // word c of agent a at [c * A_T + a]: candidate bits of chunk c
+    __shared__ float s_keys[K * BA];
+    __shared__ unsigned short s_idx[K * BA];
+    __shared__ unsigned int s_mask[WW * BA];  // word c of heap column col at [c * BA + col]: candidate bits of chunk c
     __shared__ float2 s_tile[NW][C];
-    __shared__ int s_count[A_T];
+    __shared__ int s_count[BA];
 
     const float radius = d.p.observationRadius;
     const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
-    const HeapCol<A_T> heap{s_keys + a, s_idx + a};
+    const HeapCol<BA> heap{s_keys + col, s_idx + col};
     int count = 0;
 
-    if (wave * APW < n) {  // wave-uniform: waves without live agents skip the scan
+    if (a0 + wave * APW < n) {  // wave-uniform: waves without live agents skip the scan
         float ex = 0.f, ey = 0.f;
         Quat inv{1.f, 0.f, 0.f, 0.f};
         if (live) {
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                         }
                     }
                     const unsigned int word = agent_or(part);
-                    if (sub == 0) s_mask[c * A_T + a] = word;
+                    if (sub == 0) s_mask[c * BA + col] = word;
                     nz |= (word != 0u ? 1u : 0u) << c;
                 } else {
                     // AllEntitiesWithRadiusFiltering: first K in index order within the radius, sim.cpp:261-279
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                         const int t = __ffs(mine) - 1;
                         mine &= mine - 1;
                         const int pos = count + __popc(word & ((1u << t) - 1u));
-                        if (pos < K) s_idx[pos * A_T + a] = (unsigned short)(base + t);
+                        if (pos < K) s_idx[pos * BA + col] = (unsigned short)(base + t);
                     }
                     count += __popc(word);
                 }
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                         if (nz) {
                             cn = __ffs(nz) - 1;
                             nz &= nz - 1;
-                            wnx = s_mask[cn * A_T + a];
+                            wnx = s_mask[cn * BA + col];
                         }
                     };
                     fetch();
@@ -428,12 +441,13 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
         wave_sync();
         if (live && sub == 0) {
             if (knn) count = heap.radius_filter(min(R, K), radius);
-            s_count[a] = min(count, K);
+            s_count[col] = min(count, K);
         }
     }
     __syncthreads();
     if (d.debug_flags & 1) return;
-    write_rows<A_T>(d, w, n, r0, knn, s_idx, s_count, tid, NW * 64);
+    write_rows<A_T>(d, w, a0, max(0, min(BA, n - a0)), r0, knn,
+                    [&](int c, int sl) -> int { return s_idx[sl * BA + c]; }, s_count, tid, NW * 64);
 }
 
 // ---- set-order mode (gd_config.knn_order = GD_KNN_SET_ORDER) ----
@@ -566,7 +580,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         wave_sync();
     }
     __syncthreads();
-    write_rows<A_T>(d, w, n, r0, knn, s_idx, s_count, tid, NW * 64);
+    write_rows<A_T>(d, w, 0, n, r0, knn, [&](int c, int sl) -> int { return s_idx[sl * A_T + c]; }, s_count, tid, NW * 64);
 }
 
 }  // namespace
@@ -578,8 +592,10 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         else hipLaunchKernelGGL((k_map_obs_set<128, 8>), grid, dim3(512), 0, st, d);
         return;
     }
-    if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64, 4, 14>), grid, dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((k_map_obs<128, 8, 14>), grid, dim3(512), 0, st, d);
+    constexpr int NW = GD_MAP_OBS_NW;
+    const int blocks = ((d.W + 7) / 8) * 8 * (d.A / (16 * NW));
+    if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64, NW, 14>), dim3(blocks), dim3(NW * 64), 0, st, d);
+    else hipLaunchKernelGGL((k_map_obs<128, NW, 14>), dim3(blocks), dim3(NW * 64), 0, st, d);
 }
 
 }  // namespace gd
