@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=91)
     ap.add_argument("--worlds", type=int, default=1024, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=64, choices=(64, 128))
-    ap.add_argument("--roofline-steps", type=int, default=40)
+    ap.add_argument("--roofline-steps", type=int, default=91, help="separately timed stretch for per-kernel HIP-event timing: one whole episode")
     ap.add_argument("--workloads", default="synthetic,waymo,lidar,rl_loop",
                     help="first = primary; synthetic | waymo | lidar (Waymo tiles + 360-degree LiDAR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                     for (int k = 0; k < PL; k++) {
                         const int t = sub * PL + k;
                         const float2 xy = tile[t];
-                        const bool pass = live && t < tn && !(sqrtf(ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y)) > radius);
+                        const bool pass = live && t < tn && !(ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y) > d.radius_key_max);
                         part |= (pass ? 1u : 0u) << t;
                     }
                     const unsigned int word = agent_or(part);
@@ -468,7 +468,6 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
     const int n = d.shape[w * 2 + 0];
     const int r0 = d.road_off[w];
     const int R = d.road_off[w + 1] - r0;
-    const float radius = d.p.observationRadius;
     const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
 
     constexpr int CAP = 1024;  // in-radius candidates a wave can hold in LDS
@@ -491,25 +490,37 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         // gather the in-radius candidates (key, road) in road order: lane = road, 64 consecutive roads per
         // iteration in one coalesced load issued an iteration ahead (the world's (x, y) stream is re-read
         // per agent from L1/L2; it reaches HBM once), ballot compaction into the wave's LDS buffer
+        const float kmax = d.radius_key_max;
         auto in_radius = [&](float key) -> bool {
-            // radiusFilter keeps length() <= radius (src/knn.hpp:88); the linear scan skips length() > radius
-            return knn ? (sqrtf(key) <= radius) : !(sqrtf(key) > radius);
+            // radiusFilter keeps length() <= radius (src/knn.hpp:88); the linear scan skips length() > radius.
+            // sqrtf is monotone and correctly rounded, so both are comparisons of the squared key with
+            // radius_key_max, the largest fp32 whose square root is <= radius (computed at gd_create)
+            return knn ? (key <= kmax) : !(key > kmax);
         };
         const float2 *rxy = d.road_xy + r0;
         int nin = 0;
-        float2 xy_next = lane < R ? rxy[lane] : make_float2(0.f, 0.f);
-        for (int rb = 0; rb < R; rb += 64) {
-            const float2 xy = xy_next;
-            const int rn = rb + 64 + lane;
-            if (rn < R) xy_next = rxy[rn];
-            const int r = rb + lane;
-            const float key = ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y);
-            const bool in = r < R && in_radius(key);
-            const unsigned long long b = __ballot(in);
-            if (b == 0ull) continue;  // wave-uniform
-            const int pos = nin + __popcll(b & lower);
-            if (in && pos < CAP) { ckey[pos] = key; cidx[pos] = (unsigned short)r; }
-            nin += __popcll(b);
+        constexpr int U = 4;  // 64-road groups per iteration: U loads in flight per lane, issued an iteration ahead
+        float2 nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) nxt[u] = u * 64 + lane < R ? rxy[u * 64 + lane] : make_float2(0.f, 0.f);
+        for (int rb = 0; rb < R; rb += 64 * U) {
+            float2 cur[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                cur[u] = nxt[u];
+                const int rn = rb + 64 * U + u * 64 + lane;
+                if (rn < R) nxt[u] = rxy[rn];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int r = rb + u * 64 + lane;
+                const float key = ego_dist2(ex, ey, inv.w, inv.z, cur[u].x, cur[u].y);
+                const bool in = r < R && in_radius(key);
+                const unsigned long long b = __ballot(in);
+                const int pos = nin + __popcll(b & lower);
+                if (in && pos < CAP) { ckey[pos] = key; cidx[pos] = (unsigned short)r; }
+                nin += __popcll(b);
+            }
         }
         wave_sync();
         int count = 0;
@@ -517,16 +528,26 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
             // every in-radius road (k-NN), or the first K of them (linear scan), in road order
             count = min(nin, K);
             for (int j = lane; j < count; j += 64) s_idx[j * A_T + a] = cidx[j];
-        } else if (nin <= CAP) {
+        } else if (nin < CAP) {
             // K smallest by (key, road): bisection on the key bits for the K-th smallest key T
             // (largest T with count(key < T) < K), then everything below T plus the earliest ties
+            // three probes per pass (counts packed 11 + 11 + 10 bits, nin < 1024: one cross-lane reduction
+            // for all three): the search interval shrinks four-fold per pass, 16 passes for the 31 key bits
             unsigned int lo = 0u, hi = 0x7f800000u;
             while (lo < hi) {
-                const unsigned int mid = lo + (hi - lo + 1) / 2;
-                int cnt = 0;
-                for (int j = lane; j < nin; j += 64) cnt += __float_as_uint(ckey[j]) < mid ? 1 : 0;
-                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-                if (cnt < K) lo = mid; else hi = mid - 1;
+                const unsigned int step = (hi - lo + 3u) / 4u;  // >= 1
+                const unsigned int p1 = lo + step, p2 = min(hi, p1 + step), p3 = min(hi, p2 + step);
+                unsigned int cnt = 0;
+                for (int j = lane; j < nin; j += 64) {
+                    const unsigned int kb = __float_as_uint(ckey[j]);
+                    cnt += (kb < p1 ? 1u : 0u) + (kb < p2 ? 1u << 11 : 0u) + (kb < p3 ? 1u << 22 : 0u);
+                }
+                for (int off = 32; off > 0; off >>= 1) cnt += (unsigned int)__shfl_xor((int)cnt, off);
+                const int c1 = (int)(cnt & 2047u), c2 = (int)((cnt >> 11) & 2047u), c3 = (int)(cnt >> 22);
+                if (c3 < K) lo = p3;
+                else if (c2 < K) { lo = p2; hi = p3 - 1u; }
+                else if (c1 < K) { lo = p1; hi = p2 - 1u; }
+                else hi = p1 - 1u;
             }
             int less = 0;
             for (int j = lane; j < nin; j += 64) less += __float_as_uint(ckey[j]) < lo ? 1 : 0;
