@@ -57,7 +57,7 @@ def scenes_for(workload, worlds, rank):
     return sharding.scene_list_for_rank(WAYMO, worlds, rank)
 
 
-def make_sim(scenes, kw, agents, device_index, knn_order=0, lidar_half_angle=0.0):
+def make_sim(scenes, kw, agents, device_index, knn_order=0, lidar_half_angle=0.0, enable_bev=False):
     import madrona_gpudrive as mg
     p = mg.Parameters()
     for k, v in kw.items():
@@ -66,7 +66,7 @@ def make_sim(scenes, kw, agents, device_index, knn_order=0, lidar_half_angle=0.0
         else:
             setattr(p, k, v)
     return mg.SimManager(exec_mode=mg.madrona.ExecMode.CUDA, gpu_id=device_index, scenes=scenes, params=p,
-                         max_agents=agents, knn_order=knn_order, lidar_half_angle=lidar_half_angle)
+                         max_agents=agents, knn_order=knn_order, lidar_half_angle=lidar_half_angle, enable_bev=enable_bev)
 
 
 def action_batches(worlds, agents, device, seed, n=8):
@@ -108,7 +108,8 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
     scenes = scenes_for(workload, args.worlds, rank)
     t0 = time.time()
     sim = make_sim(scenes, kw, args.agents, local_rank, knn_order=args.knn_order,
-                   lidar_half_angle=float(np.pi) if workload == "lidar" else 0.0)  # 360 degrees
+                   lidar_half_angle=float(np.pi) if workload == "lidar" else 0.0,  # 360 degrees
+                   enable_bev=workload == "bev")  # the reference rasterises the 200 x 200 BEV on every step
     torch.cuda.synchronize(device)
     init_s = time.time() - t0
     shape = sim.shape_tensor().to_torch().cpu().numpy()
@@ -145,6 +146,8 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
     names = {0: "k_world_step", 1: "k_map_obs"}
     if workload == "lidar":
         names[2] = "k_lidar"
+    if workload == "bev":
+        names[3] = "k_bev"
     kt = {}
     for kid, name in names.items():
         ms, n = sim.kernel_timing_read(kid)
@@ -222,7 +225,7 @@ def main():
     ap.add_argument("--worlds", type=int, default=1024, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=64, choices=(64, 128))
     ap.add_argument("--roofline-steps", type=int, default=91, help="separately timed stretch for per-kernel HIP-event timing: one whole episode")
-    ap.add_argument("--workloads", default="synthetic,waymo,lidar,rl_loop",
+    ap.add_argument("--workloads", default="synthetic,waymo,lidar,bev,rl_loop",
                     help="first = primary; synthetic | waymo | lidar (Waymo tiles + 360-degree LiDAR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default=None, choices=(None, "nccl", "gloo"),

@@ -21,7 +21,7 @@ constexpr int RES = GD_BEV_RES;
 // ------------------------------------------------------------------------------------------
 struct BevEnt {
     float cx, cy, cosy, siny, half_l, half_w;
-    int gx, gy, br, type;
+    int x0, x1, y0, y1, type;  // cell range to test (inclusive)
 };
 
 __device__ __forceinline__ BevEnt bev_entity(float cx, float cy, float yaw, float length, float width, int type,
@@ -34,13 +34,22 @@ __device__ __forceinline__ BevEnt bev_entity(float cx, float cy, float yaw, floa
     const float scale_px = (2 * radius) / RES;
     const float scale_m = RES / (2 * radius);
     int gx = (int)((cx + radius) * scale_m), gy = (int)((cy + radius) * scale_m);
-    e.gx = min(max(0, gx), RES - 1);
-    e.gy = min(max(0, gy), RES - 1);
+    gx = min(max(0, gx), RES - 1);
+    gy = min(max(0, gy), RES - 1);
     const float max_side = fmaxf(e.half_w, e.half_l);
-    e.br = (int)ceilf(sqrtf(2 * (max_side * max_side)) / scale_px);
+    const int br = (int)ceilf(sqrtf(2 * (max_side * max_side)) / scale_px);
     e.cosy = p_cos(-yaw);
     e.siny = p_sin(-yaw);
     e.type = type;
+    // The reference tests every cell of the square (gx, gy) +- br (the circumscribed circle's box around the
+    // CLAMPED centre cell).  The cells that can pass the rotated-rectangle test also lie in the rectangle's
+    // axis-aligned box (one cell of margin): testing the intersection paints the identical cell set.
+    const float hx = e.half_l * fabsf(e.cosy) + e.half_w * fabsf(e.siny) + 2e-3f;
+    const float hy = e.half_l * fabsf(e.siny) + e.half_w * fabsf(e.cosy) + 2e-3f;
+    const int tx0 = (int)floorf((cx - hx + radius) * scale_m) - 1, tx1 = (int)ceilf((cx + hx + radius) * scale_m) + 1;
+    const int ty0 = (int)floorf((cy - hy + radius) * scale_m) - 1, ty1 = (int)ceilf((cy + hy + radius) * scale_m) + 1;
+    e.x0 = max(max(gx - br, 0), tx0); e.x1 = min(min(gx + br, RES - 1), tx1);
+    e.y0 = max(max(gy - br, 0), ty0); e.y1 = min(min(gy + br, RES - 1), ty1);
     return e;
 }
 
@@ -123,22 +132,41 @@ __global__ __launch_bounds__(256) void k_bev(DevSim d) {
     const int ne = s_ne;
 
     // ---- paint: wave `wave` owns rows [50*wave, 50*wave + 50) ----
+    // 64 entities at a time, one per lane: a ballot names the ones whose cell range meets this wave's rows,
+    // and only those are painted, in entity order (ascending lane, ascending batch), their parameters
+    // broadcast to the wave as scalars.
     const int row_lo = wave * (RES / 4), row_hi = row_lo + RES / 4 - 1;
     const float scale_px = (2 * radius) / RES;
-    for (int e = 0; e < ne; e++) {
-        const BevEnt en = s_ent[e];
-        const int y0 = max(max(en.gy - en.br, 0), row_lo), y1 = min(min(en.gy + en.br, RES - 1), row_hi);
-        const int x0 = max(en.gx - en.br, 0), x1 = min(en.gx + en.br, RES - 1);
-        if (y1 < y0 || x1 < x0) continue;  // wave-uniform
-        const int nx = x1 - x0 + 1, cells = nx * (y1 - y0 + 1);
-        for (int c = lane; c < cells; c += 64) {
-            const int y = y0 + c / nx, x = x0 + c - (c / nx) * nx;
-            const float px = x * scale_px - radius, py = y * scale_px - radius;
-            const float ldx = px - en.cx, ldy = py - en.cy;
-            const float lx = ldx * en.cosy - ldy * en.siny;
-            const float ly = ldx * en.siny + ldy * en.cosy;
-            const float epsilon = 1e-3f;
-            if (fabsf(lx) <= en.half_l + epsilon && fabsf(ly) <= en.half_w + epsilon) s_grid[y * RES + x] = (unsigned char)en.type;
+    auto bcast_f = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+    for (int eb = 0; eb < ne; eb += 64) {
+        const int e = eb + lane;
+        BevEnt mine{};
+        if (e < ne) mine = s_ent[e];
+        const int my0 = max(mine.y0, row_lo), my1 = min(mine.y1, row_hi);
+        unsigned long long todo = __ballot(e < ne && my1 >= my0 && mine.x1 >= mine.x0);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const float cx = bcast_f(mine.cx, l), cy = bcast_f(mine.cy, l);
+            const float cosy = bcast_f(mine.cosy, l), siny = bcast_f(mine.siny, l);
+            const float half_l = bcast_f(mine.half_l, l), half_w = bcast_f(mine.half_w, l);
+            const int x0 = __builtin_amdgcn_readlane(mine.x0, l), x1 = __builtin_amdgcn_readlane(mine.x1, l);
+            const int y0 = __builtin_amdgcn_readlane(my0, l), y1 = __builtin_amdgcn_readlane(my1, l);
+            const unsigned char type = (unsigned char)__builtin_amdgcn_readlane(mine.type, l);
+            const int nx = x1 - x0 + 1, cells = nx * (y1 - y0 + 1);
+            const float inv_nx = 1.f / (float)nx;
+            for (int c = lane; c < cells; c += 64) {
+                int q = (int)(((float)c + 0.5f) * inv_nx);  // c / nx for c < 40,000 (checked and corrected below)
+                q -= q * nx > c ? 1 : 0;
+                q += (q + 1) * nx <= c ? 1 : 0;
+                const int y = y0 + q, x = x0 + c - q * nx;
+                const float px = x * scale_px - radius, py = y * scale_px - radius;
+                const float ldx = px - cx, ldy = py - cy;
+                const float lx = ldx * cosy - ldy * siny;
+                const float ly = ldx * siny + ldy * cosy;
+                const float epsilon = 1e-3f;
+                if (fabsf(lx) <= half_l + epsilon && fabsf(ly) <= half_w + epsilon) s_grid[y * RES + x] = type;
+            }
         }
     }
     __syncthreads();
