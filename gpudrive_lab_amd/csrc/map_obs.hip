@@ -113,13 +113,15 @@ struct HeapCol {
     // patched where the pop rewrote them and come back holding the chain's new contents, qk[0] being
     // the new root key.  There are no data-dependent loops and no serial predicate chains.
     static constexpr int Q[7] = {0, 2, 5, 11, 24, 49, 99};
-    __device__ __forceinline__ void load_chain(float (&qk)[7], unsigned int (&qi)[7]) const {
+    __device__ __forceinline__ void load_chain(float (&qk)[7], unsigned int (&qi)[7], float &lk, unsigned int &li) const {
 #pragma unroll
         for (int l = 0; l < 7; l++) { qk[l] = key(Q[l]); qi[l] = index(Q[l]); }
+        lk = key(K - 1);
+        li = index(K - 1);
     }
-    __device__ __forceinline__ void replace_top(float yk, unsigned int yi, float (&qk)[7], unsigned int (&qi)[7]) const {
-        const float lk = key(K - 1);
-        const unsigned int li = index(K - 1);
+    // `lk` / `li`: slot K-1, which only this function touches during a replay, also stays in registers.
+    __device__ __forceinline__ void replace_top(float yk, unsigned int yi, float (&qk)[7], unsigned int (&qi)[7], float &lk,
+                                                unsigned int &li) const {
         int ph[8];
         float ck[7];
         unsigned int ci[7];
@@ -205,6 +207,7 @@ struct HeapCol {
         for (int u = 0; u < 8; u++) set(u == 7 ? K - 1 : Q[u], ok[u], (unsigned short)oi[u]);
 #pragma unroll
         for (int u = 0; u < 7; u++) { qk[u] = ok[u]; qi[u] = oi[u]; }
+        lk = ok[7]; li = oi[7];
     }
     // radiusFilter, src/knn.hpp:83-97 (swap-remove in heap-array order); returns newBeyond
     __device__ __forceinline__ int radius_filter(int len, float radius) const {
@@ -430,13 +433,15 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs(DevSim d) {
                     if (has) xy_cur = rxy[r_cur];
                     float qk[7];  // ancestor chain of slot K-1 incl. the root: qk[0] is the K-th distance
                     unsigned int qi[7];
-                    heap.load_chain(qk, qi);
+                    float lk;
+                    unsigned int li;
+                    heap.load_chain(qk, qi, lk, li);
                     while (has) {
                         const bool has_n = next(r_nxt);
                         float2 xy_nxt = xy_cur;
                         if (has_n) xy_nxt = rxy[r_nxt];
                         const float key = ego_dist2(ex, ey, inv.w, inv.z, xy_cur.x, xy_cur.y);
-                        if (key < qk[0]) heap.replace_top(key, (unsigned int)r_cur, qk, qi);
+                        if (key < qk[0]) heap.replace_top(key, (unsigned int)r_cur, qk, qi, lk, li);
                         r_cur = r_nxt;
                         xy_cur = xy_nxt;
                         has = has_n;
