@@ -9,7 +9,10 @@
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <atomic>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.hpp"
@@ -283,6 +286,35 @@ struct gd_sim {
             up(d.shape + static_cast<size_t>(w0) * 2, st.shape.data(), st.shape.size() * 4);
             st = Staging();
         };
+        // Parse the distinct scenes of this call on a few host threads first: MapReader::parseAndWriteOut runs
+        // on ONE thread per set_maps in the reference (src/mgr.cpp:630-647), ~9 ms of JSON per scene here.
+        {
+            std::vector<std::string> todo;
+            for (int w : sorted_worlds)
+                if (scene_cache.emplace(scenes[w], nullptr).second) todo.push_back(scenes[w]);
+            std::vector<std::shared_ptr<const gd::SceneMap>> parsed(todo.size());
+            std::vector<std::exception_ptr> errors(todo.size());
+            const unsigned hc = std::thread::hardware_concurrency();
+            const size_t nthreads = std::min<size_t>(todo.size(), std::min<size_t>(16, hc ? hc : 1));
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (size_t k; (k = next.fetch_add(1)) < todo.size();) {
+                    try {
+                        parsed[k] = gd::load_scene(todo[k], params.polylineReductionThreshold);
+                    } catch (...) {
+                        errors[k] = std::current_exception();
+                    }
+                }
+            };
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker);
+            worker();
+            for (auto &t : pool) t.join();
+            for (size_t k = 0; k < todo.size(); k++) {
+                if (errors[k]) std::rethrow_exception(errors[k]);  // first failing scene in world order
+                scene_cache[todo[k]] = parsed[k];
+            }
+        }
         int run_start = -1, run_len = 0;
         for (int w : sorted_worlds) {
             if (run_len > 0 && (w != run_start + run_len || run_len == kRun)) {
@@ -303,9 +335,7 @@ struct gd_sim {
             if (it != world_cache.end()) {
                 hw = it->second;
             } else {
-                auto sit = scene_cache.find(path);
-                if (sit == scene_cache.end())
-                    sit = scene_cache.emplace(path, gd::load_scene(path, params.polylineReductionThreshold)).first;
+                auto sit = scene_cache.find(path);  // filled above
                 hw = std::make_shared<gd::HostWorld>();
                 gd::build_host_world(*sit->second, params, A, del, ndel, *hw);
                 world_cache.emplace(key, hw);
