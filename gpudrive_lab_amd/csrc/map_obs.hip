@@ -8,18 +8,20 @@
 //
 //   * one 200-entry heap per agent in LDS, slot-major (keys[slot][agent]) so that an agent's
 //     lane always hits its own bank whatever slot it touches;
-//   * a workgroup per world, NW waves, each wave owning 64/G agents with G lanes per agent;
-//   * SCAN (all 64 lanes): roads are processed in windows of 14 x 32; each 32-road chunk is staged
-//     in a per-wave LDS tile (one coalesced load; road bytes reach HBM once per world, L2 serves
-//     the other waves), every lane tests its share of the chunk against the agent's K-th distance
-//     at the window start (a conservative superset of the true inserts), and a ballot folds the
-//     results into one candidate bit-mask word per (agent, chunk), in road order;
-//   * DRAIN (one lane per agent): each agent walks the set bits of its window masks at its own
-//     pace, re-tests the candidate against the live heap top and replays the reference's
-//     pop_heap / push_heap.  Long windows even out the candidate counts of the lanes of a wave
-//     (road polylines are spatially coherent: per 32-road chunk the busiest agent has ~8x the
-//     mean), which is what bounds the replay.
+//   * workgroups of NW waves, 16 agents per wave, 4 lanes per agent; a world with more than 16 NW
+//     agent slots is several workgroups, placed on one XCD;
+//   * SCAN (all 64 lanes): roads are processed in windows (2 x 32 over the first 512 roads, then
+//     14 x 32); each 32-road chunk is staged in a per-wave LDS tile (one coalesced load issued two
+//     chunks ahead; road bytes reach HBM once per world), every lane tests its 8 roads of the chunk
+//     against the agent's K-th distance at the window start (a conservative superset of the true
+//     inserts), and two cross-lane ORs fold the results into one candidate word per (agent, chunk);
+//   * DRAIN (one lane per agent): each agent walks the set bits of its window words at its own
+//     pace, re-tests the candidate against the live K-th distance and replays the reference's
+//     pop_heap / push_heap as straight-line code (HeapCol::replace_top).
 //
+// What bounds it: LDS holds 128 agents per CU, every insert of an agent is a
+// link of a serial chain, and one wave issues one vector instruction per 4 cycles whatever else is
+// resident: time = 2 generations x lock-step rounds per wave x instructions per round x 4 cycles.
 // The wave never synchronises with the other waves of the workgroup until the final write-out.
 #include <hip/hip_runtime.h>
 
