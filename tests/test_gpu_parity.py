@@ -82,6 +82,10 @@ LOCKSTEP = [
     ("linear_roads_fork128", [SCENE_4, TEST_JSON], 128, 30,
      dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
           distanceToGoalThreshold=2.0, roadObservationAlgorithm=1, dynamicsModel=0, **ALL_OBJECTS)),
+    # this fork's kMaxAgentCount with more than 64 live agents (81 objects): the road kernel runs two workgroups per world
+    ("knn_fork128", [SCENE_4, SCENE_407, SCENE_4], 128, 25,
+     dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1,
+          distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)),
     ("state_model", [SCENE_407], 64, 10,
      dict(polylineReductionThreshold=0.5, observationRadius=50.0, collisionBehaviour=2, rewardType=0,
           distanceToGoalThreshold=2.0, dynamicsModel=3, **ALL_OBJECTS)),
@@ -364,6 +368,7 @@ EDGE_SCENES = [
     ("single_agent", 1, 8, 65),          # N = 1: all partner rows are the id -2 padding
     ("more_objects_than_slots", 90, 6, 65),   # 90 objects, 64 agent slots
     ("road_cap", 6, 40, 301),            # 12,000 segments: capped at kMaxRoadEntityCount = 10,000
+    ("fork128_full", 128, 16, 129),      # A = 128 slots all live (140 objects): both 64-agent workgroups of a world busy
 ]
 
 
@@ -374,14 +379,16 @@ def test_edge_case_scenes(oracle_mod, tmp_path, name, n_agents, n_poly, pts, roa
     import json
     from gpudrive_lab_amd import synth
     path = tmp_path / (name + ".json")
-    path.write_text(json.dumps(synth.make_scene(17, n_agents=n_agents, n_polylines=n_poly, pts_per_polyline=pts)))
+    A = 128 if name.startswith("fork128") else 64
+    n_objects = n_agents + 12 if name.startswith("fork128") else n_agents
+    path.write_text(json.dumps(synth.make_scene(17, n_agents=n_objects, n_polylines=n_poly, pts_per_polyline=pts)))
     kw = dict(polylineReductionThreshold=0.0, observationRadius=40.0, collisionBehaviour=0, rewardType=1,
               distanceToGoalThreshold=2.0, dynamicsModel=0, roadObservationAlgorithm=road_alg, **ALL_OBJECTS)
     scenes = [str(path), SCENE_407]  # ragged batch: the edge world next to an ordinary one
-    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
-    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    gpu = P.make_gpu_sim(scenes, max_agents=A, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=A, **kw)
     shape = np.asarray(orc.shape_tensor())
-    assert shape[0, 0] == min(n_agents, 64) and shape[0, 1] == min(n_poly * (pts - 1), 10000)
+    assert shape[0, 0] == min(n_agents, A) and shape[0, 1] == min(n_poly * (pts - 1), 10000)
     P.compare_fresh(gpu, orc)
     P.lockstep(gpu, orc, 4, 0, seed=21)
     gpu.close()
