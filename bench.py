@@ -46,6 +46,8 @@ def params_for(workload):
     kw["polylineReductionThreshold"] = 0.0 if workload in ("synthetic", "rl_loop") else 0.1
     if workload == "lidar":  # BASELINE configs[4]: LiDAR 3 x 50 rays, mixed vehicle / cyclist / pedestrian agents
         kw["enableLidar"] = 1
+    if workload == "cfg3":   # BASELINE configs[2]: 4 x the worlds, collisions stop agents, goal-reach reward
+        kw["collisionBehaviour"] = 0
     return kw
 
 
@@ -105,6 +107,8 @@ def bench_workload(workload, args, rank, local_rank, world, device):
 
 def _bench_workload(workload, args, rank, local_rank, world, device):
     kw = params_for(workload)
+    if workload == "cfg3":
+        args = argparse.Namespace(**dict(vars(args), worlds=4 * args.worlds))
     scenes = scenes_for(workload, args.worlds, rank)
     t0 = time.time()
     sim = make_sim(scenes, kw, args.agents, local_rank, knn_order=args.knn_order,
@@ -225,7 +229,7 @@ def main():
     ap.add_argument("--worlds", type=int, default=1024, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=64, choices=(64, 128))
     ap.add_argument("--roofline-steps", type=int, default=91, help="separately timed stretch for per-kernel HIP-event timing: one whole episode")
-    ap.add_argument("--workloads", default="synthetic,waymo,lidar,bev,rl_loop",
+    ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop",
                     help="first = primary; synthetic | waymo | lidar (Waymo tiles + 360-degree LiDAR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default=None, choices=(None, "nccl", "gloo"),
