@@ -74,3 +74,18 @@ def test_two_rank_gloo_gather_and_reductions(tmp_path):
         outs.append(out)
         assert p.returncode == 0, out
     assert all("ok" in o for o in outs)
+
+
+def test_scene_tiling_matches_reference_dataloader_golden():
+    """Rank 0's scene list is what the reference's SceneDataLoader yields when the dataset is smaller than the
+    batch (tests/golden/make_dataset_tiling_golden.py, generated with gpudrive/env/dataset.py itself); the
+    other ranks continue the same round-robin where the previous rank stopped."""
+    import json
+    import os
+    from gpudrive_lab_amd import sharding
+    root = os.path.dirname(os.path.abspath(__file__))
+    for case in json.load(open(os.path.join(root, "golden", "dataset_tiling_golden.json"))):
+        files = list(range(case["n_files"]))
+        assert sharding.scene_list_for_rank(files, case["batch"], 0) == case["indices"]
+        two = sharding.scene_list_for_rank(files, case["batch"], 0) + sharding.scene_list_for_rank(files, case["batch"], 1)
+        assert two == [files[i % len(files)] for i in range(2 * case["batch"])]
