@@ -1,0 +1,114 @@
+"""Column contract of the exported tensors (gpudrive_lab_amd/columns.py).
+
+(1) against golden vectors decoded by the reference's own Python classes (tests/golden/make_columns_golden.py);
+(2) cross-tensor invariants that only hold if the columns mean what the reference says they mean: the
+    partner / road rows of an ego must be the ego-frame image of the other entity's ABSOLUTE row.
+The invariant check is shared with the GPU suite (tests/test_gpu_parity.py runs it on the HIP path)."""
+import os
+
+import numpy as np
+
+from gpudrive_lab_amd import columns as COL
+from tests.conftest import ROOT, SCENE_4, TEST_JSON
+
+AGENT_SCALE = np.float32(0.7)  # madrona_gpudrive.vehicleScale
+
+
+def test_columns_match_reference_decoders():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "columns_golden.npz"))
+    raws = dict(SELF_OBS="raw_self_obs", ABS_OBS="raw_abs_obs", PARTNER_OBS="raw_partner", ROAD_ROW_local="raw_roadmap",
+                ROAD_ROW_global="raw_map_obs", INFO="raw_info", METADATA="raw_metadata")
+    checked = 0
+    for key in g.files:
+        if key.startswith("raw_") or key.startswith("RESPONSE_TYPE"):
+            continue
+        table, name = key.split(".")
+        cmap = getattr(COL, table.split("_local")[0].split("_global")[0])
+        raw = g[raws[table]]
+        sel = raw[..., cmap[name]]
+        if name in COL.SCALED_BY_AGENT_SCALE.get(table, ()):
+            sel = sel * AGENT_SCALE
+        if table == "INFO" and name == "collided":
+            sel = sel.sum(-1)
+        exp = g[key]
+        if table == "PARTNER_OBS":
+            exp = exp[..., 0]  # the reference unsqueezes every partner field
+        if table == "ROAD_ROW_local" and name == "type":
+            sel = sel.astype(np.int64)
+        assert sel.shape == exp.shape and np.array_equal(sel, exp), key
+        checked += 1
+    assert checked == 52
+    resp = g["raw_response"][..., 0]
+    for name, val in COL.RESPONSE_TYPE.items():
+        assert np.array_equal(g["RESPONSE_TYPE." + name], resp == val)
+
+
+def wrap(a):
+    return (a + np.pi) % (2 * np.pi) - np.pi
+
+
+def check_cross_tensor_invariants(sim, as_numpy=np.array, atol=2e-4):
+    """Partner and road rows are the ego-frame image of the absolute rows; self rows agree with absolute rows."""
+    ab = as_numpy(sim.absolute_self_observation_tensor()).astype(np.float64)
+    so = as_numpy(sim.self_observation_tensor()).astype(np.float64)
+    po = as_numpy(sim.partner_observations_tensor()).astype(np.float64)
+    rm = as_numpy(sim.agent_roadmap_tensor()).astype(np.float64)
+    mo = as_numpy(sim.map_observation_tensor()).astype(np.float64)
+    shape = as_numpy(sim.shape_tensor())
+    A, C, P, R = COL.ABS_OBS, COL.SELF_OBS, COL.PARTNER_OBS, COL.ROAD_ROW
+    n_pairs = n_roads = 0
+    for w in range(ab.shape[0]):
+        n, nr = int(shape[w, 0]), int(shape[w, 1])
+        pos = ab[w, :n][:, [A["pos_x"], A["pos_y"]]]
+        yaw = ab[w, :n, A["rotation_angle"]]
+        q = ab[w, :n, A["rotation_as_quaternion"]]
+        assert np.allclose(2 * np.arctan2(q[:, 3], q[:, 0]), yaw, atol=1e-5) or np.allclose(wrap(2 * np.arctan2(q[:, 3], q[:, 0]) - yaw), 0, atol=1e-5)
+        c, s = np.cos(yaw), np.sin(yaw)
+        to_ego = lambda i, v: np.stack([c[i] * v[..., 0] + s[i] * v[..., 1], -s[i] * v[..., 0] + c[i] * v[..., 1]], -1)
+        # self rows: goal in the ego frame, sizes and ids shared with the absolute row
+        goal = ab[w, :n][:, [A["goal_x"], A["goal_y"]]]
+        for i in range(n):
+            assert np.allclose(to_ego(i, goal[i] - pos[i]), so[w, i, [C["rel_goal_x"], C["rel_goal_y"]]], atol=atol)
+        assert np.array_equal(so[w, :n, C["id"]], ab[w, :n, A["id"]])
+        assert np.allclose(so[w, :n, C["vehicle_length"]], ab[w, :n, A["vehicle_length"]])
+        ids = ab[w, :n, A["id"]]
+        for i in range(n):
+            others = [j for j in range(n) if j != i]  # OtherAgents order: agent index order skipping self
+            for k, j in enumerate(others):
+                row = po[w, i, k]
+                if row[P["ids"]] < 0:
+                    continue  # beyond the observation radius: zero() row with id -1
+                assert row[P["ids"]] == ids[j]
+                assert np.allclose(to_ego(i, pos[j] - pos[i]), row[[P["rel_pos_x"], P["rel_pos_y"]]], atol=atol)
+                assert abs(wrap(row[P["orientation"]] - (yaw[j] - yaw[i]))) < 1e-4
+                assert np.isclose(row[P["vehicle_length"]], ab[w, j, A["vehicle_length"]]) and np.isclose(row[P["speed"]], so[w, j, C["speed"]], atol=1e-5)
+                n_pairs += 1
+            assert (po[w, i, n - 1:, P["ids"]] == -2).all()  # zero_nonexist() rows
+            # road rows: matched to the global rows through (id, type, length) and the ego-frame position
+            gl = mo[w, :nr]
+            for row in rm[w, i]:
+                if row[R["type"]] == 0 and row[R["id"]] <= 0 and row[R["segment_length"]] == 0:
+                    continue  # padding
+                cand = gl[(gl[:, R["id"]] == row[R["id"]]) & (gl[:, R["type"]] == row[R["type"]])]
+                img = to_ego(i, cand[:, [R["x"], R["y"]]] - pos[i])
+                dist = np.abs(img - row[[R["x"], R["y"]]]).max(-1)
+                m = int(np.argmin(dist))
+                assert dist[m] < atol, (w, i, row)
+                assert np.isclose(cand[m, R["segment_length"]], row[R["segment_length"]])
+                assert abs(wrap(row[R["orientation"]] - (cand[m, R["orientation"]] - yaw[i]))) < 1e-4
+                n_roads += 1
+    return n_pairs, n_roads
+
+
+def test_cross_tensor_invariants_on_the_oracle(oracle_mod):
+    O = oracle_mod
+    p = O.default_params(polylineReductionThreshold=0.1, observationRadius=40.0, collisionBehaviour=2, rewardType=1,
+                         distanceToGoalThreshold=2.0, isStaticAgentControlled=1, initOnlyValidAgentsAtFirstStep=0)
+    sim = O.OracleSim([TEST_JSON, SCENE_4], p, max_agents=64)
+    rng = np.random.default_rng(9)
+    for _ in range(5):
+        act = sim.action_tensor()
+        act[..., 0] = rng.uniform(-1, 2, act.shape[:2]); act[..., 1] = rng.uniform(-0.5, 0.5, act.shape[:2])
+        sim.step()
+    n_pairs, n_roads = check_cross_tensor_invariants(sim)
+    assert n_pairs > 500 and n_roads > 1500
