@@ -100,6 +100,43 @@ def check_cross_tensor_invariants(sim, as_numpy=np.array, atol=2e-4):
     return n_pairs, n_roads
 
 
+def check_road_selection_by_brute_force(sim, radius, as_numpy=np.array, K=200, margin=1e-3):
+    """k-NN mode, independent of the oracle: the non-padding road rows of an agent are exactly the global roads
+    that are among its K nearest AND within the radius (roads within `margin` of either boundary may go both ways)."""
+    ab = as_numpy(sim.absolute_self_observation_tensor()).astype(np.float64)
+    rm = as_numpy(sim.agent_roadmap_tensor()).astype(np.float64)
+    mo = as_numpy(sim.map_observation_tensor()).astype(np.float64)
+    shape = as_numpy(sim.shape_tensor())
+    A, R = COL.ABS_OBS, COL.ROAD_ROW
+    checked = 0
+    for w in range(ab.shape[0]):
+        n, nr = int(shape[w, 0]), int(shape[w, 1])
+        gl = mo[w, :nr]
+        for i in range(n):
+            pos = ab[w, i, [A["pos_x"], A["pos_y"]]]
+            yaw = ab[w, i, A["rotation_angle"]]
+            d = np.hypot(gl[:, R["x"]] - pos[0], gl[:, R["y"]] - pos[1])
+            kth = np.sort(d)[min(K, nr) - 1] if nr else 0.0
+            must = (d < min(kth, radius) - margin)                      # certainly selected
+            may = (d <= min(kth, radius) + margin)                      # possibly selected
+            rows = rm[w, i]
+            rows = rows[~((rows[:, R["type"]] == 0) & (rows[:, R["segment_length"]] == 0) & (rows[:, R["id"]] <= 0))]
+            # map every row back to a global road through its ego-frame position
+            c, s_ = np.cos(yaw), np.sin(yaw)
+            gx = pos[0] + c * rows[:, R["x"]] - s_ * rows[:, R["y"]]
+            gy = pos[1] + s_ * rows[:, R["x"]] + c * rows[:, R["y"]]
+            hit = np.zeros(nr, int)
+            for x, y, t in zip(gx, gy, rows[:, R["type"]]):
+                m = int(np.argmin(np.hypot(gl[:, R["x"]] - x, gl[:, R["y"]] - y) + 1e3 * (gl[:, R["type"]] != t)))
+                assert np.hypot(gl[m, R["x"]] - x, gl[m, R["y"]] - y) < 1e-3
+                hit[m] += 1
+            assert len(rows) <= K
+            assert (hit[must] >= 1).all(), (w, i, "a road that must be selected is missing")
+            assert (hit[~may] == 0).all(), (w, i, "a road outside the K nearest / the radius was selected")
+            checked += 1
+    return checked
+
+
 def test_cross_tensor_invariants_on_the_oracle(oracle_mod):
     O = oracle_mod
     p = O.default_params(polylineReductionThreshold=0.1, observationRadius=40.0, collisionBehaviour=2, rewardType=1,
@@ -112,3 +149,15 @@ def test_cross_tensor_invariants_on_the_oracle(oracle_mod):
         sim.step()
     n_pairs, n_roads = check_cross_tensor_invariants(sim)
     assert n_pairs > 500 and n_roads > 1500
+    assert check_road_selection_by_brute_force(sim, 40.0) == 25 + 64
+
+
+def test_road_selection_by_brute_force_when_K_binds(oracle_mod):
+    """Unreduced polylines (9,899 roads) and a 100 m radius: far more than K roads are in radius, so the K-th
+    distance, not the radius, decides."""
+    O = oracle_mod
+    p = O.default_params(polylineReductionThreshold=0.0, observationRadius=100.0, collisionBehaviour=2,
+                         initOnlyValidAgentsAtFirstStep=0)
+    sim = O.OracleSim([TEST_JSON], p, max_agents=64)
+    assert int(sim.shape_tensor()[0, 1]) == 9899
+    assert check_road_selection_by_brute_force(sim, 100.0) == 25

@@ -362,7 +362,7 @@ def test_episode_tracker_matches_oracle(oracle_mod, reward_type, behaviour):
 def test_cross_tensor_invariants_on_the_hip_path():
     """The column contract (gpudrive_lab_amd/columns.py) on the device tensors: partner and road rows are the
     ego-frame image of the absolute rows (tests/test_columns.py, no oracle involved)."""
-    from tests.test_columns import check_cross_tensor_invariants
+    from tests.test_columns import check_cross_tensor_invariants, check_road_selection_by_brute_force
     kw = dict(polylineReductionThreshold=0.1, observationRadius=40.0, collisionBehaviour=2, rewardType=1,
               distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
     gpu = P.make_gpu_sim([TEST_JSON, SCENE_4], max_agents=64, **kw)
@@ -370,8 +370,10 @@ def test_cross_tensor_invariants_on_the_hip_path():
     for _ in range(5):
         P.write_actions(gpu, P.random_actions(rng, 2, 64, 0))
         gpu.step()
-    n_pairs, n_roads = check_cross_tensor_invariants(gpu, as_numpy=lambda t: t.to_torch().cpu().numpy())
+    as_np = lambda t: t.to_torch().cpu().numpy()
+    n_pairs, n_roads = check_cross_tensor_invariants(gpu, as_numpy=as_np)
     assert n_pairs > 500 and n_roads > 1500
+    assert check_road_selection_by_brute_force(gpu, 40.0, as_numpy=as_np) == 25 + 64  # k-NN set, no oracle
     gpu.close()
 
 
