@@ -571,7 +571,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                 const unsigned int kb = j < nin ? __float_as_uint(ckey[j]) : 0xffffffffu;
                 const bool tie = kb == lo;
                 const unsigned long long tb = __ballot(tie);
-                const bool take = kb < lo || (tie && __popcll(tb & lower) < need_ties);
+                const bool take = kb < lo || (tie && (int)__popcll(tb & lower) < need_ties);
                 need_ties -= min(need_ties, __popcll(tb));
                 const unsigned long long kb2 = __ballot(take);
                 if (take) s_idx[(count + __popcll(kb2 & lower)) * A_T + a] = cidx[j];
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                 const unsigned int kb = key_bits(rb + lane, in);
                 const bool tie = in && kb == lo;
                 const unsigned long long tb = __ballot(tie);
-                const bool take = (in && kb < lo) || (tie && __popcll(tb & lower) < need_ties);
+                const bool take = (in && kb < lo) || (tie && (int)__popcll(tb & lower) < need_ties);
                 need_ties -= min(need_ties, __popcll(tb));
                 const unsigned long long kb2 = __ballot(take);
                 if (take) s_idx[(count + __popcll(kb2 & lower)) * A_T + a] = (unsigned short)(rb + lane);
