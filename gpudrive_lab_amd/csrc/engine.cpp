@@ -388,7 +388,7 @@ struct gd_sim {
         if (nroad > road_cap) {
             if (d_road_xy) (void)hipFree(d_road_xy);
             if (d_road_aux) (void)hipFree(d_road_aux);
-            road_cap = nroad + nroad / 8 + 64;
+            road_cap = nroad + nroad / 8 + 320;  // k_map_obs requests chunks of 32 roads up to 256 roads past a world's last one
             HIP_CHECK(hipMalloc(&d_road_xy, road_cap * sizeof(float) * 2));
             HIP_CHECK(hipMalloc(&d_road_aux, road_cap * sizeof(float) * 8));
         }
@@ -576,7 +576,6 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
             while (sqrtf(std::nextafterf(k, INFINITY)) <= r) k = std::nextafterf(k, INFINITY);
             d.radius_key_max = r >= 0.f ? k : -1.f;
         }
-        d.debug_flags = std::getenv("GPUDRIVE_DEBUG_FLAGS") ? std::atoi(std::getenv("GPUDRIVE_DEBUG_FLAGS")) : 0;
         d.action = static_cast<float *>(s->exported[GD_T_ACTION]);
         d.reward = static_cast<float *>(s->exported[GD_T_REWARD]);
         d.done = static_cast<int32_t *>(s->exported[GD_T_DONE]);
@@ -608,6 +607,8 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.goal_x = s->alloc_internal<float>(WA); d.goal_y = s->alloc_internal<float>(WA);
         d.etype = s->alloc_internal<int32_t>(WA); d.agent_id = s->alloc_internal<int32_t>(WA);
         d.resp = s->alloc_internal<int32_t>(WA);
+        d.sel_idx = s->alloc_internal<uint16_t>(static_cast<size_t>(WA) * GD_MAP_OBS_K);
+        d.sel_count = s->alloc_internal<int32_t>(WA);
         d.reset_flags = s->alloc_internal<int32_t>(W);
         d.rebuilt_flags = s->alloc_internal<int32_t>(W);
         d.any_reset = s->alloc_internal<int32_t>(1);

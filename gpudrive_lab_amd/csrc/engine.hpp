@@ -31,7 +31,6 @@ struct DevSim {
     int knn_order;    // GD_KNN_*
     float lidar_half_angle;  // 0 -> pi/3 (reference consts::lidarAngle)
     float radius_key_max;    // largest fp32 k with sqrtf(k) <= observationRadius (radiusFilter on squared keys)
-    int debug_flags;  // developer ablation switches (GPUDRIVE_DEBUG_FLAGS), 0 in production
     gd_params p;
     // exported
     float *action, *reward, *self_obs, *abs_obs, *partner, *agent_map, *map_obs, *lidar, *bev, *traj, *means;
@@ -42,6 +41,9 @@ struct DevSim {
     int32_t *collided;
     float *len, *wid, *hgt, *sc0, *sc1, *goal_x, *goal_y;
     int32_t *etype, *agent_id, *resp;
+    // road selection scratch: what k_map_obs / k_map_obs_set hand to k_map_rows
+    uint16_t *sel_idx;    // [W][A][K] road index (within the world) of every selected slot, in output order
+    int32_t *sel_count;   // [W][A] selected rows per agent (rows beyond it are padding)
     // per world flags
     int32_t *reset_flags, *rebuilt_flags;
     int32_t *any_reset;    // one int: k_episode_step raised at least one reset flag in this step

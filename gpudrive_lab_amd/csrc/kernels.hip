@@ -299,7 +299,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         constexpr int P = STEP_THREADS / A_T;
         const int ag = a % A_T, part = a / A_T;
         const int my_fl = ag < n ? s_flags[ag] : 0;
-        if ((my_fl & 1) && !(d.debug_flags & 16)) {
+        if (my_fl & 1) {
             Obb me;
             {
                 float *mf = reinterpret_cast<float *>(&me);
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
 
     // ---- collectPartnerObsSystem, :188-240.  One thread per (ego, slot) row so that a wave
     // writes 64 consecutive 36-byte rows. ----
-    if (!d.p.disableClassicalObs && !(d.debug_flags & 8)) {
+    if (!d.p.disableClassicalObs) {
         const int rows = n * (A_T - 1);
         float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
         for (int p = a; p < rows; p += STEP_THREADS) {
