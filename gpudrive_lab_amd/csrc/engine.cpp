@@ -441,6 +441,15 @@ struct gd_sim {
             d.cell_items = static_cast<const int32_t *>(d_cell_items);
         }
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.road_off), road_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
+        {
+            // longest-first launch order of the road kernel: its time per world grows with the road count
+            std::vector<int32_t> order(W);
+            for (int w = 0; w < W; w++) order[w] = w;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                return road_off[x + 1] - road_off[x] > road_off[y + 1] - road_off[y];
+            });
+            HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.world_order), order.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
+        }
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.box_off), box_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
         d.road_xy = static_cast<const float2 *>(d_road_xy);
         d.road_aux = static_cast<const float4 *>(d_road_aux);
@@ -614,6 +623,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.any_reset = s->alloc_internal<int32_t>(1);
         d.gate_any = 0;
         d.road_off = s->alloc_internal<int32_t>(W + 1);
+        d.world_order = s->alloc_internal<int32_t>(W);
         d.box_off = s->alloc_internal<int32_t>(W + 1);
         d.grid = s->alloc_internal<gd::GridHdr>(W);
         for (int i = 0; i < gd_sim::kRing; i++) {

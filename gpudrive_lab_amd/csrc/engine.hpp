@@ -51,6 +51,7 @@ struct DevSim {
                            // every workgroup returns at once unless *any_reset is set
     // roads
     const int32_t *road_off;  // [W+1]
+    const int32_t *world_order;  // [W] worlds by decreasing road count: the road kernel starts its longest workgroups first
     const float2 *road_xy;
     const float4 *road_aux;
     const int32_t *box_off;   // [W+1]

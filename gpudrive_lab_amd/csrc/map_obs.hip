@@ -52,8 +52,16 @@ namespace gd {
 namespace {
 
 constexpr int K = GD_MAP_OBS_K;
-constexpr int LW = 64;        // lanes of a wave = agent slots per workgroup of the reference-order kernel
-constexpr int SLOTS = K + 2;  // stored slots 1..K (the heap), K+1 and K+2 (sentinels); slot g is row g - 1
+#ifndef GD_TRIG_NUM
+#define GD_TRIG_NUM 4  // eighths of the live lanes that must be idle before the next chunk is scanned
+#endif
+#ifndef GD_MAP_OBS_AW
+#define GD_MAP_OBS_AW 32
+#endif
+constexpr int AW = GD_MAP_OBS_AW;  // agents (heap columns) per workgroup = per wave of the reference-order kernel
+constexpr int G = 64 / AW;         // lanes per agent: lane = sub * AW + column
+constexpr int SLOTS = K + 2;       // stored slots 1..K (the heap), K+1 and K+2 (sentinels); slot g is row g - 1
+static_assert(AW == 16 || AW == 32 || AW == 64, "agents per wave");
 
 // Intra-wave ordering point for LDS traffic between lanes of one wave.
 __device__ __forceinline__ void wave_sync() {
@@ -62,20 +70,21 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Column of lane `l` in the u16 index array: lanes l and l + 32 share a dword, so the 32 lanes of
-// either half of the wave (the LDS services them separately) touch 32 different banks.
-__device__ __forceinline__ int idx_col(int l) { return (l & 31) * 2 + (l >> 5); }
+// Position of column `c` in a row of the u16 index array.  With 64 columns, c and c + 32 share a dword, so the
+// 32 lanes of either half of the wave (the LDS services them separately) touch 32 different banks.
+__device__ __forceinline__ int idx_col(int c) { return AW == 64 ? (c & 31) * 2 + (c >> 5) : c; }
 
 // One agent's heap: a column of the wave's LDS arrays.  Slot g (1-based; the reference's array index is
-// g - 1) is at k[g * LW] / i[g * LW].
+// g - 1) is at k[g * AW] / i[g * AW].  With G > 1 lanes per agent, every lane of an agent holds the same state and
+// runs the same code; `owner` (sub-lane 0) is the one that stores.
 struct Heap {
     float *k;
     unsigned short *i;
-    __device__ __forceinline__ float key(int g) const { return k[g * LW]; }
-    __device__ __forceinline__ unsigned int index(int g) const { return i[g * LW]; }
+    __device__ __forceinline__ float key(int g) const { return k[g * AW]; }
+    __device__ __forceinline__ unsigned int index(int g) const { return i[g * AW]; }
     __device__ __forceinline__ void set(int g, float key, unsigned int idx) const {
-        k[g * LW] = key;
-        i[g * LW] = (unsigned short)idx;
+        k[g * AW] = key;
+        i[g * AW] = (unsigned short)idx;
     }
     __device__ __forceinline__ void move(int dst, int src) const { set(dst, key(src), index(src)); }
     // make_heap, src/binary_heap.hpp:170-185.  The reference sifts parents K/2, ..., 1 in turn; parents on one tree
@@ -120,31 +129,36 @@ struct Heap {
             }
         }
     }
+    // The parents of a level are dealt round-robin to the G lanes of the agent (lane `sub` takes first + sub,
+    // first + sub + G, ...), N at a time per lane; the caller separates levels with wave_sync().
     template <int L, int N>
-    __device__ __forceinline__ void make_level(int first, int last) const {
-        int p = first;
+    __device__ __forceinline__ void make_level(int first, int last, int sub) const {
+        int p = first + sub * N;
 #pragma clang loop unroll(disable)
-        for (; p + N - 1 <= last; p += N) {
+        for (; p + N - 1 <= last; p += N * G) {
             int start[N];
 #pragma unroll
             for (int j = 0; j < N; j++) start[j] = p + j;
             sift_level<L, N>(start);
         }
+        if (N > 1) {
 #pragma clang loop unroll(disable)
-        for (; p <= last; p++) {
-            const int start[1] = {p};
-            sift_level<L, 1>(start);
+            for (; p <= last; p++) {  // fewer than N left for this lane
+                const int start[1] = {p};
+                sift_level<L, 1>(start);
+            }
         }
     }
     // len == K (the only length the reference ever heapifies, src/knn.hpp:128)
-    __device__ __forceinline__ void make() const {
-        make_level<6, 4>(64, K / 2);
-        make_level<5, 4>(32, 63);
-        make_level<4, 4>(16, 31);
-        make_level<3, 4>(8, 15);
-        make_level<2, 4>(4, 7);
-        make_level<1, 2>(2, 3);
-        make_level<0, 1>(1, 1);
+    __device__ __forceinline__ void make(int sub) const {
+        constexpr int N = G == 1 ? 4 : 1;
+        make_level<6, N>(64, K / 2, sub); wave_sync();
+        make_level<5, N>(32, 63, sub); wave_sync();
+        make_level<4, N>(16, 31, sub); wave_sync();
+        make_level<3, N>(8, 15, sub); wave_sync();
+        make_level<2, G == 1 ? 4 : 1>(4, 7, sub); wave_sync();
+        make_level<1, G == 1 ? 2 : 1>(2, 3, sub); wave_sync();
+        make_level<0, 1>(1, 1, sub); wave_sync();
     }
     // pop_heap + replace last + push_heap (src/knn.hpp:138-151) as straight-line code.
     //
@@ -154,33 +168,62 @@ struct Heap {
     // lets x rest at level 6 at the latest -- then pushes the old last element x up from the leaf hole.
     // The values x meets on its way up are exactly the children just moved, which are still in
     // registers, so its climb needs no LDS read.  push_heap then lifts the new element y from slot K
-    // along the fixed ancestor chain 100, 50, 25, 12, 6, 3, 1.  The caller keeps those seven slots in
-    // registers across calls (`qk`/`qi`, level l = slot Q[l]; load_chain() fills them); they are
-    // patched where the pop rewrote them and come back holding the chain's new contents, qk[0] being
-    // the new root key.  Slot K itself lives in `lk`/`li` for the whole replay (store_last() writes it
-    // back).  There are no data-dependent loops and no serial predicate chains, every LDS read is
-    // speculative (its address is in bounds whatever the lane's state) and only the stores and the
-    // register updates depend on `valid`.
-    static constexpr int Q[7] = {1, 3, 6, 12, 25, 50, 100};
-    __device__ __forceinline__ void load_chain(float (&qk)[7], unsigned int (&qi)[7], float &lk, unsigned int &li) const {
+    // along the fixed ancestor chain 100, 50, 25, 12, 6, 3, 1.
+    //
+    // State kept in registers for the whole replay (struct Top; load() / store() move it from / to LDS):
+    //   * slots 1..7 (tree levels 0..2), keys and indices: the first two decisions of every pop and the top of
+    //     the push chain need no LDS at all, and those slots are never written to LDS during the replay
+    //     (LDS stores are the most expensive instructions of the round, and the next round's first read
+    //     queues behind them);
+    //   * the deeper chain slots 12, 25, 50, 100 (qk / qi; they are also kept current in LDS, where the pop
+    //     reads them as ordinary children) and slot K (lk / li; its LDS copy holds the sentinel -1).
+    // There are no data-dependent loops and no serial predicate chains: one basic block, executed by the lanes that
+    // have an insert this round (a VALU instruction costs a lone wave the same 4 cycles whatever its EXEC mask, so
+    // what counts is the instruction count: 16 selects per round to keep the idle lanes' state were more expensive
+    // than the EXEC region).  With several lanes per agent only `owner` stores.
+    struct Top {
+        float tk[8];         // tk[g], g = 1..7; tk[1] is the K-th distance
+        unsigned int ti[8];
+        float qk[4];         // slots 12, 25, 50, 100
+        unsigned int qi[4];
+        float lk;            // slot K
+        unsigned int li;
+    };
+    static constexpr int QD[4] = {12, 25, 50, 100};
+    __device__ __forceinline__ void load(Top &t) const {
 #pragma unroll
-        for (int l = 0; l < 7; l++) { qk[l] = key(Q[l]); qi[l] = index(Q[l]); }
-        lk = key(K);
-        li = index(K);
-        k[K * LW] = -1.f;  // slot K lives in registers during the replay; its LDS copy is a third sentinel
+        for (int g = 1; g < 8; g++) { t.tk[g] = key(g); t.ti[g] = index(g); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { t.qk[u] = key(QD[u]); t.qi[u] = index(QD[u]); }
+        t.lk = key(K);
+        t.li = index(K);
+        k[K * AW] = -1.f;  // slot K lives in registers during the replay; its LDS copy is a third sentinel
     }
-    __device__ __forceinline__ void store_last(float lk, unsigned int li) const { set(K, lk, li); }
-    __device__ __forceinline__ void replace_top(bool valid, float yk, unsigned int yi, float (&qk)[7], unsigned int (&qi)[7],
-                                                float &lk, unsigned int &li) const {
+    __device__ __forceinline__ void store(const Top &t) const {
+#pragma unroll
+        for (int g = 1; g < 8; g++) set(g, t.tk[g], t.ti[g]);
+        set(K, t.lk, t.li);
+    }
+    __device__ __forceinline__ void replace_top(bool owner, float yk, unsigned int yi, Top &t) const {
         int g[8];
         float ck[7];
         unsigned int ci[7];
         g[0] = 1;
-        // Decisions use keys only, two levels per LDS round trip: the hole's two children AND its four
-        // grandchildren are fetched together, so the 6 unconditional levels cost 3 dependent round
-        // trips; the index of a chosen child is requested as soon as the child is known.
+        // levels 0 and 1 out of registers
+        const bool r0 = !(t.tk[3] < t.tk[2]);
+        ck[0] = r0 ? t.tk[3] : t.tk[2];
+        ci[0] = r0 ? t.ti[3] : t.ti[2];
+        g[1] = 2 + (r0 ? 1 : 0);
+        const float hl = r0 ? t.tk[6] : t.tk[4], hr = r0 ? t.tk[7] : t.tk[5];
+        const unsigned int il = r0 ? t.ti[6] : t.ti[4], ir = r0 ? t.ti[7] : t.ti[5];
+        const bool r1 = !(hr < hl);
+        ck[1] = r1 ? hr : hl;
+        ci[1] = r1 ? ir : il;
+        g[2] = 2 * g[1] + (r1 ? 1 : 0);
+        // levels 2..5: decisions use keys only, two levels per LDS round trip (the hole's two children AND its
+        // four grandchildren are fetched together); the index of a chosen child is requested as soon as it is known
 #pragma unroll
-        for (int l = 0; l < 6; l += 2) {
+        for (int l = 2; l < 6; l += 2) {
             const int cb = 2 * g[l];  // children cb, cb + 1; grandchildren 2 cb .. 2 cb + 3
             const float kl = key(cb), kr = key(cb + 1);
             const float g0 = key(2 * cb), g1 = key(2 * cb + 1), g2 = key(2 * cb + 2), g3 = key(2 * cb + 3);
@@ -188,9 +231,9 @@ struct Heap {
             ck[l] = right ? kr : kl;
             g[l + 1] = cb + (right ? 1 : 0);
             ci[l] = index(g[l + 1]);
-            const float hl = right ? g2 : g0, hr = right ? g3 : g1;
-            const bool right2 = !(hr < hl);
-            ck[l + 1] = right2 ? hr : hl;
+            const float gl = right ? g2 : g0, gr = right ? g3 : g1;
+            const bool right2 = !(gr < gl);
+            ck[l + 1] = right2 ? gr : gl;
             g[l + 2] = 2 * g[l + 1] + (right2 ? 1 : 0);
             ci[l + 1] = index(g[l + 2]);
         }
@@ -212,56 +255,76 @@ struct Heap {
         // For the keys this is the median of (ck[l-1], ck[l], lk) since ck[l-1] >= ck[l].
         bool c[8];
 #pragma unroll
-        for (int l = 0; l < 7; l++) c[l] = ck[l] < lk;
+        for (int l = 0; l < 7; l++) c[l] = ck[l] < t.lk;
         c[7] = true;
         float nk[8];
         unsigned int ni[8];
         const float inf = __builtin_inff();
 #pragma unroll
         for (int l = 0; l < 8; l++) {
-            nk[l] = __builtin_amdgcn_fmed3f(l > 0 ? ck[l - 1] : inf, l < 7 ? ck[l] : -1.f, lk);
-            ni[l] = c[l] ? li : (l < 7 ? ci[l] : 0u);
+            nk[l] = __builtin_amdgcn_fmed3f(l > 0 ? ck[l - 1] : inf, l < 7 ? ck[l] : -1.f, t.lk);
+            ni[l] = c[l] ? t.li : (l < 7 ? ci[l] : 0u);
             if (l > 0) ni[l] = c[l - 1] ? ci[l - 1] : ni[l];
         }
-        // current values of the ancestor chain of slot K (patched where the pop rewrote a slot)
-        float pk[7];
-        unsigned int pi[7];
-        pk[0] = nk[0]; pi[0] = ni[0];
+        // slots 1..7 after the pop
+        float pk[8];
+        unsigned int pi[8];
+        pk[1] = nk[0]; pi[1] = ni[0];
+        pk[2] = r0 ? t.tk[2] : nk[1]; pi[2] = r0 ? t.ti[2] : ni[1];
+        pk[3] = r0 ? nk[1] : t.tk[3]; pi[3] = r0 ? ni[1] : t.ti[3];
 #pragma unroll
-        for (int l = 1; l < 7; l++) {
-            const bool rewritten = g[l] == Q[l];  // g[l] lives on level l, like Q[l]
-            pk[l] = rewritten ? nk[l] : qk[l];
-            pi[l] = rewritten ? ni[l] : qi[l];
+        for (int j = 4; j < 8; j++) {
+            const bool hit = (r0 == ((j & 2) != 0)) && (r1 == ((j & 1) != 0));  // g[2] == j
+            pk[j] = hit ? nk[2] : t.tk[j];
+            pi[j] = hit ? ni[2] : t.ti[j];
         }
-        // y climbs from slot K along the chain; the chain is non-increasing towards the leaf, so
-        // p[u] = pk[u] < yk is monotone as well: chain position u (7 = slot K) receives
-        // q[u-1] if p[u-1], y if p[u] && !p[u-1], and keeps its value otherwise (median again).
+        // the deeper chain slots after the pop (patched where the path went through them)
+        float dk[4];
+        unsigned int di[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool rewritten = g[u + 3] == QD[u];  // g[l] lives on level l, like the chain slot of that level
+            dk[u] = rewritten ? nk[u + 3] : t.qk[u];
+            di[u] = rewritten ? ni[u + 3] : t.qi[u];
+        }
+        // y climbs from slot K along the chain 100, 50, 25, 12, 6, 3, 1 (levels 6..0): with the chain as
+        // q[0..6] = slots 1, 3, 6, 12, 25, 50, 100, non-increasing towards the leaf, p[u] = q[u] < yk is monotone as
+        // well: chain position u (7 = slot K) receives q[u-1] if p[u-1], y if p[u] && !p[u-1], and keeps its value
+        // otherwise (median again).
+        const float q[7] = {pk[1], pk[3], pk[6], dk[0], dk[1], dk[2], dk[3]};
+        const unsigned int qx[7] = {pi[1], pi[3], pi[6], di[0], di[1], di[2], di[3]};
         bool p[8];
 #pragma unroll
-        for (int u = 0; u < 7; u++) p[u] = pk[u] < yk;
+        for (int u = 0; u < 7; u++) p[u] = q[u] < yk;
         p[7] = true;
         float ok[8];
         unsigned int oi[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            ok[u] = __builtin_amdgcn_fmed3f(u > 0 ? pk[u - 1] : inf, u < 7 ? pk[u] : -1.f, yk);
-            oi[u] = p[u] ? yi : (u < 7 ? pi[u] : 0u);
-            if (u > 0) oi[u] = p[u - 1] ? pi[u - 1] : oi[u];
+            ok[u] = __builtin_amdgcn_fmed3f(u > 0 ? q[u - 1] : inf, u < 7 ? q[u] : -1.f, yk);
+            oi[u] = p[u] ? yi : (u < 7 ? qx[u] : 0u);
+            if (u > 0) oi[u] = p[u - 1] ? qx[u - 1] : oi[u];
         }
-        // the register state is updated with selects, outside the predicated region: everything above stays
-        // speculative (computed by every lane in one block) and only the stores are predicated
+        pk[1] = ok[0]; pi[1] = oi[0];
+        pk[3] = ok[1]; pi[3] = oi[1];
+        pk[6] = ok[2]; pi[6] = oi[2];
 #pragma unroll
-        for (int u = 0; u < 7; u++) {
-            qk[u] = valid ? ok[u] : qk[u];
-            qi[u] = valid ? oi[u] : qi[u];
+        for (int j = 1; j < 8; j++) {
+            t.tk[j] = pk[j];
+            t.ti[j] = pi[j];
         }
-        lk = valid ? ok[7] : lk;
-        li = valid ? oi[7] : li;
-        if (valid) {
 #pragma unroll
-            for (int l = 0; l < 8; l++) set(g[l], nk[l], ni[l]);
+        for (int u = 0; u < 4; u++) {
+            t.qk[u] = ok[u + 3];
+            t.qi[u] = oi[u + 3];
+        }
+        t.lk = ok[7];
+        t.li = oi[7];
+        if (owner) {
 #pragma unroll
-            for (int u = 0; u < 7; u++) set(Q[u], ok[u], oi[u]);
+            for (int l = 3; l < 8; l++) set(g[l], nk[l], ni[l]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) set(QD[u], ok[u + 3], oi[u + 3]);
         }
     }
     // radiusFilter, src/knn.hpp:83-97: swap-remove in heap-array order; returns newBeyond.  `kmax` is the largest
@@ -270,8 +333,8 @@ struct Heap {
     // until an in-radius one lands there.  With m in-radius elements the outcome is: the holes (out-of-radius
     // slots below m, ascending) receive the in-radius elements of [m, len) in DESCENDING slot order, everything
     // else below m stays.  So: one pass for the in-radius flags (`flags`: 7 words of this lane in LDS, word w at
-    // flags[w * LW]), then one move per hole.
-    __device__ __forceinline__ int radius_filter(int len, float kmax, unsigned int *flags) const {
+    // flags[w * AW]), then one move per hole.
+    __device__ __forceinline__ int radius_filter(int len, float kmax, unsigned int *flags, bool owner) const {
         int m = 0;
 #pragma unroll
         for (int w = 0; w < (K + 31) / 32; w++) {
@@ -281,9 +344,10 @@ struct Heap {
                 const int s = w * 32 + b;
                 if (s < K) f |= (s < len && key(s + 1) <= kmax) ? 1u << b : 0u;
             }
-            flags[w * LW] = f;
+            if (owner) flags[w * AW] = f;
             m += __popc(f);
         }
+        wave_sync();
         if (m < len) {
             auto below = [](int limit, int w) -> unsigned int {  // bits of word w whose slot is < limit
                 const int n = limit - w * 32;
@@ -291,27 +355,65 @@ struct Heap {
             };
             int hw = 0, dw = (len - 1) >> 5;
             unsigned int holes = ~flags[0] & below(m, 0);
-            unsigned int donors = flags[dw * LW] & ~below(m, dw);
+            unsigned int donors = flags[dw * AW] & ~below(m, dw);
             for (;;) {
                 while (holes == 0u && (hw + 1) * 32 < m) {
                     hw++;
-                    holes = ~flags[hw * LW] & below(m, hw);
+                    holes = ~flags[hw * AW] & below(m, hw);
                 }
                 if (holes == 0u) break;
                 while (donors == 0u) {  // as many donors as holes: never runs off the array
                     dw--;
-                    donors = flags[dw * LW] & ~below(m, dw);
+                    donors = flags[dw * AW] & ~below(m, dw);
                 }
                 const int hole = hw * 32 + __ffs(holes) - 1;
                 holes &= holes - 1u;
                 const int db = 31 - __clz(donors);
                 donors &= ~(1u << db);
-                move(hole + 1, dw * 32 + db + 1);
+                if (owner) move(hole + 1, dw * 32 + db + 1);
             }
         }
         return m;
     }
 };
+
+// Per-agent cursor over the ring of candidate words, and one round of the drain.
+constexpr int RING = 16;  // chunks of candidate words an agent may lag behind the scan
+constexpr int C = 32;     // roads per chunk = one candidate word
+struct Drain {
+    unsigned int word = 0;  // unread candidate bits of chunk `cw`
+    unsigned int nz = 0;    // ring slots that hold an unread, non-empty word of this agent
+    int cw = 0;
+    bool has = false;       // (r_cur, xy_cur) is a candidate whose (x, y) has been requested
+    int r_cur = 0;
+    float2 xy_cur = {0.f, 0.f};
+    __device__ __forceinline__ bool pending() const { return has || word != 0u || nz != 0u; }
+};
+// One candidate per agent: the candidate fetched in the previous round is keyed exactly as the reference does
+// (gd_math.hpp ego_dist2), re-tested against the live K-th distance and replayed; meanwhile the next one is popped
+// (oldest unread ring word if the current one is used up, its lowest bit) and its (x, y) requested.  `ring` is
+// this agent's column of the ring (slot c at ring[c * AW]), `head` the number of chunks scanned so far.
+__device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Drain &s, const unsigned int *ring, const float2 *rxy,
+                                            int head, float ex, float ey, float iw, float iz, bool owner) {
+    const bool refill = s.word == 0u && s.nz != 0u;
+    const unsigned int rot = (s.nz | (s.nz << RING)) >> ((unsigned int)head & (RING - 1));  // bit j: chunk head - RING + j
+    const int c_new = head - RING + (__ffs(rot) - 1);
+    const unsigned int slot_new = (unsigned int)c_new & (RING - 1);
+    const unsigned int fetched = ring[slot_new * AW];
+    const unsigned int word = refill ? fetched : s.word;
+    const int cw = refill ? c_new : s.cw;
+    const bool has_n = word != 0u;
+    const int r_nxt = K + cw * C + (__ffs(word) - 1);
+    const float2 xy_nxt = rxy[has_n ? r_nxt : 0];
+    const float key = ego_dist2(ex, ey, iw, iz, s.xy_cur.x, s.xy_cur.y);
+    if (s.has && key < top.tk[1]) heap.replace_top(owner, key, (unsigned int)s.r_cur, top);  // lanes without an insert sit the block out
+    s.nz = refill ? s.nz & ~(1u << slot_new) : s.nz;
+    s.word = word & (word - 1u);
+    s.cw = cw;
+    s.has = has_n;
+    s.r_cur = r_nxt;
+    s.xy_cur = xy_nxt;
+}
 
 // ---- row write-out (both selection kernels end by handing their selection to this one) ----
 // One thread per (world, agent, slot) row of agent_roadmap_tensor; a wave writes 64 consecutive 36-byte rows.  The row is
@@ -324,7 +426,14 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     const size_t wa = p / K;
     const int s = (int)(p - wa * K);
     const int w = (int)(wa / A_T), a = (int)(wa - (size_t)w * A_T);
-    if (w >= d.W || a >= d.shape[w * 2 + 0]) return;  // rows of padding agents are written at reset (k_init_padding_rows)
+    if (w >= d.W) return;
+    // everything the row needs besides the road itself is requested at once (one round trip, not a chain of them)
+    const int n = d.shape[w * 2 + 0];
+    const int cnt = d.sel_count[wa];
+    const int r0 = d.road_off[w];
+    const int sel = (int)d.sel_idx[p];
+    const float ex = d.px[wa], ey = d.py[wa], ew = d.qw[wa], ez = d.qz[wa];
+    if (a >= n) return;  // rows of padding agents are written at reset (k_init_padding_rows)
     // The rows are written once and not read again by the step: streaming (nt) stores keep them from pushing the
     // road and agent arrays, which every step re-reads, out of L2 / Infinity Cache.
     float *o = d.agent_map + p * 9;
@@ -333,18 +442,18 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
         __builtin_nontemporal_store(v3, o + 3); __builtin_nontemporal_store(v4, o + 4); __builtin_nontemporal_store(v5, o + 5);
         __builtin_nontemporal_store(v6, o + 6); __builtin_nontemporal_store(v7, o + 7); __builtin_nontemporal_store(v8, o + 8);
     };
-    if (s >= d.sel_count[wa]) {
+    if (s >= cnt) {
         // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
         // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
         const float pad = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST ? 0.f : -1.f;
         put(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (float)ET_None, pad, pad);
         return;
     }
-    const int r = d.road_off[w] + (int)d.sel_idx[p];
+    const int r = r0 + sel;
     const float2 xy = d.road_xy[r];
     const float4 q0 = d.road_aux[(size_t)r * 2], q1 = d.road_aux[(size_t)r * 2 + 1];
-    const Quat einv = quat_inv(quat_from_wz(d.qw[wa], d.qz[wa]));
-    const V2 rel = ego_relative(d.px[wa], d.py[wa], einv, xy.x, xy.y);
+    const Quat einv = quat_inv(quat_from_wz(ew, ez));
+    const V2 rel = ego_relative(ex, ey, einv, xy.x, xy.y);
     put(rel.x, rel.y, q0.z, q0.w, q1.x, quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0.x, q0.y))), q1.y, q1.z, q1.w);
 }
 
@@ -362,35 +471,35 @@ __device__ __forceinline__ void store_selection(const DevSim &d, int w, int a0, 
     for (int col = tid; col < na; col += nthreads) d.sel_count[wa0 + col] = count_of(col);
 }
 
-// ---- reference row order: one wave per 64 agent slots of a world, one lane per agent ----
+// ---- reference row order: one wave per AW agent slots of a world, G = 64 / AW lanes per agent ----
 template <int A_T>
-__global__ __launch_bounds__(LW) void k_map_obs(DevSim d) {
-    constexpr int C = 32;          // roads per chunk = one candidate word
-    constexpr int RING = 16;       // chunks of candidate words a lane may lag behind the scan
-    constexpr int BPW = A_T / LW;  // workgroups per world
-    static_assert(BPW * LW == A_T, "geometry");
+__global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
+    constexpr int PL = C / G;      // roads of a chunk per lane
+    constexpr int BPW = A_T / AW;  // workgroups per world
+    static_assert(BPW * AW == A_T, "geometry");
     const int lane = threadIdx.x;
-    const int w = (int)blockIdx.x / BPW;
-    const int a0 = ((int)blockIdx.x % BPW) * LW;
+    const int col = lane % AW, sub = lane / AW;
+    const bool owner = sub == 0;
+    const int w = d.world_order[(int)blockIdx.x / BPW];  // longest worlds first
+    const int a0 = ((int)blockIdx.x % BPW) * AW;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int n = d.shape[w * 2 + 0];
     if (a0 >= n) return;  // rows of padding agents are written at reset (k_init_padding_rows)
     const int r0 = d.road_off[w];
     const int R = d.road_off[w + 1] - r0;
-    const int a = a0 + lane;
+    const int a = a0 + col;
     const bool live = a < n;
     const size_t i = (size_t)w * A_T + a;
 
     // one buffer, carved by hand: the ring comes first so that the 1-based heap columns (row g - 1 of the arrays,
     // i.e. base - one row + g rows) never form an address below the buffer
-    __shared__ __attribute__((aligned(16))) unsigned char s_buf[RING * LW * 4 + SLOTS * LW * 6 + LW * 4];
-    unsigned int *s_ring = reinterpret_cast<unsigned int *>(s_buf);  // word of ring slot c of lane l at [c * LW + l]
-    float *s_keys = reinterpret_cast<float *>(s_buf + RING * LW * 4) - LW;                        // [g * LW + lane], g >= 1
-    unsigned short *s_idx = reinterpret_cast<unsigned short *>(s_buf + RING * LW * 4 + SLOTS * LW * 4) - LW;  // [g * LW + idx_col]
-    float *s_stage = reinterpret_cast<float *>(s_buf + RING * LW * 4 + SLOTS * LW * 6);  // the chunk being scanned: (x, y) of 32 roads
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[RING * AW * 4 + SLOTS * AW * 6];
+    unsigned int *s_ring = reinterpret_cast<unsigned int *>(s_buf);  // word of ring slot c of column l at [c * AW + l]
+    float *s_keys = reinterpret_cast<float *>(s_buf + RING * AW * 4) - AW;                                    // [g * AW + col], g >= 1
+    unsigned short *s_idx = reinterpret_cast<unsigned short *>(s_buf + RING * AW * 4 + SLOTS * AW * 4) - AW;  // [g * AW + idx_col]
 
     const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
-    const Heap heap{s_keys + lane, s_idx + idx_col(lane)};
+    const Heap heap{s_keys + col, s_idx + idx_col(col)};
     const float2 *rxy = d.road_xy + r0;
     float ex = 0.f, ey = 0.f, iw = 1.f, iz = 0.f;  // pose; (iw, iz) is the INVERSE rotation
     if (live) {
@@ -398,15 +507,25 @@ __global__ __launch_bounds__(LW) void k_map_obs(DevSim d) {
         iw = d.qw[i]; iz = -d.qz[i];
     }
     // A chunk of 32 roads is one coalesced 256-byte load: lane j holds float j of (x0, y0, x1, y1, ...).  It is
-    // requested long before it is used, parked in LDS when its turn comes and read back with broadcast ds_read_b64
-    // (every lane the same address: conflict-free; v_readlane would route every value through an SGPR, and a VALU
-    // instruction that reads an SGPR a VALU instruction has just written waits for it: measured 3x the time).
-    // Reads up to 96 roads past the world's last one stay inside the array (the next world's roads or the pad).
+    // requested long before it is used; a lane picks the (x, y) of its PL roads out of the register with
+    // ds_bpermute (the LDS crossbar, no LDS memory).  Road t of a chunk belongs to lane sub = t % G of every agent.
+    // Reads up to 256 roads past the world's last one stay inside the array (the next world's roads or the pad).
     const float *rf = reinterpret_cast<const float *>(rxy);
     auto load_chunk = [&](int first_road) -> float { return rf[first_road * 2 + lane]; };
+    auto road_of = [&](int chunk_reg, int k) -> float2 {  // road t = k * G + sub of the chunk held in `chunk_reg`
+        const int t = k * G + sub;
+        return make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(8 * t, chunk_reg)),
+                           __int_as_float(__builtin_amdgcn_ds_bpermute(8 * t + 4, chunk_reg)));
+    };
+    auto agent_or = [&](unsigned int part) -> unsigned int {  // OR over the G lanes of an agent
+#pragma unroll
+        for (int st = AW; st < 64; st <<= 1) part |= (unsigned int)__shfl_xor((int)part, st);
+        return part;
+    };
     int count = 0;
 #ifdef GD_STAMPS
     unsigned long long st_scan = 0, st_drain = 0, st_rounds = 0, st_scans = 0, st_init = 0, st_filter = 0, st_wscan = 0, st_wround = 0;
+    (void)st_wround;
 #endif
     STAMP(t_begin);
 
@@ -417,26 +536,26 @@ __global__ __launch_bounds__(LW) void k_map_obs(DevSim d) {
             float pre = load_chunk(0);
 #pragma clang loop unroll(disable)
             for (int base = 0; base < nfill; base += C) {
-                s_stage[lane] = pre;
+                const int cur = __float_as_int(pre);
                 pre = load_chunk(base + C);
 #pragma unroll
-                for (int t = 0; t < C; t++) {
-                    if (base + t < nfill) {
-                        const float2 xy = reinterpret_cast<const float2 *>(s_stage)[t];
-                        heap.set(base + t + 1, ego_dist2(ex, ey, iw, iz, xy.x, xy.y), (unsigned int)(base + t));
-                    }
+                for (int k = 0; k < PL; k++) {
+                    const int t = base + k * G + sub;
+                    const float2 xy = road_of(cur, k);
+                    if (t < nfill) heap.set(t + 1, ego_dist2(ex, ey, iw, iz, xy.x, xy.y), (unsigned int)t);
                 }
             }
         }
         if (R >= K) {
-            s_keys[(K + 1) * LW + lane] = -1.f;
-            s_keys[(K + 2) * LW + lane] = -1.f;
-            heap.make();
-            float qk[7];  // ancestor chain of slot K incl. the root: qk[0] is the K-th distance
-            unsigned int qi[7];
-            float lk;
-            unsigned int li;
-            heap.load_chain(qk, qi, lk, li);
+            if (owner) {
+                s_keys[(K + 1) * AW + col] = -1.f;
+                s_keys[(K + 2) * AW + col] = -1.f;
+            }
+            wave_sync();
+            heap.make(sub);
+            Heap::Top top;  // slots 1..7, the deeper chain slots and slot K; top.tk[1] is the K-th distance
+            heap.load(top);
+            wave_sync();  // every lane of an agent has read slot K before its sentinel value is visible
 #ifdef GD_STAMPS
             st_init = __builtin_amdgcn_s_memtime() - t_begin;
 #endif
@@ -448,16 +567,12 @@ __global__ __launch_bounds__(LW) void k_map_obs(DevSim d) {
             const float det = (1.f - 2.f * z2) * (1.f - 2.f * z2) + 4.f * z2 * (iw * iw);
             const float margin = 1.00001f / fminf(det, 1.f);
             const int nch = (R - K + C - 1) / C;
-            const int trig = max(1, (min(LW, n - a0) + 3) >> 2);  // scan when this many live lanes have run dry
+            const int trig = max(1, (min(AW, n - a0) * GD_TRIG_NUM + 7) >> 3);  // scan when this many live agents have run dry
             int head = 0;                     // chunks scanned so far (wave-uniform)
-            // chunks head and head + 1 are in flight or landed: even chunks in pre_a, odd ones in pre_b (two copies of
-            // the scan code, so that the wait for the chunk being scanned never covers a younger request)
+            // chunks head and head + 1 are in flight or landed: even chunks in pre_a, odd ones in pre_b
             float pre_a = load_chunk(K), pre_b = load_chunk(K + C);
-            unsigned int word = 0, nz = 0;    // this lane's current candidate word; ring slots with unread words
-            int cw = 0;                       // chunk of `word`
-            bool has = false;                 // (r_cur, xy_cur) is a candidate whose (x, y) has been requested
-            int r_cur = 0;
-            float2 xy_cur = make_float2(0.f, 0.f);
+            Drain dr;
+            const unsigned long long agents = __ballot(live && owner);  // one bit per live agent of this wave
             auto scan_chunk = [&](float &pre) {
 #ifdef GD_STAMPS
                 {
@@ -468,106 +583,97 @@ __global__ __launch_bounds__(LW) void k_map_obs(DevSim d) {
 #endif
                 const unsigned int slot = (unsigned int)head & (RING - 1);
                 const int base = K + head * C;
-                s_stage[lane] = pre;
-                const float thr = live ? qk[0] * margin : -1.f;
-                unsigned int wd = 0;
+                const int cur = __float_as_int(pre);
+                const float thr = live ? top.tk[1] * margin : -1.f;
+                unsigned int part = 0;
 #pragma unroll
-                for (int t = 0; t < C; t++) {
-                    const float2 xy = reinterpret_cast<const float2 *>(s_stage)[t];
+                for (int k = 0; k < PL; k++) {
+                    const float2 xy = road_of(cur, k);
                     const float dx = xy.x - ex, dy = xy.y - ey;
                     const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                    wd |= d2 < thr ? 1u << t : 0u;
+                    part |= (d2 < thr ? 1u : 0u) << (k * G + sub);
                 }
                 pre = load_chunk(base + 2 * C);
+                unsigned int wd = agent_or(part);
                 const int tn = R - base;
                 wd &= tn >= C ? 0xffffffffu : (1u << tn) - 1u;
-                s_ring[slot * LW + lane] = wd;
-                nz |= (wd != 0u ? 1u : 0u) << slot;
+                if (owner) s_ring[slot * AW + col] = wd;
+                dr.nz |= (wd != 0u ? 1u : 0u) << slot;
                 head++;
 #ifdef GD_STAMPS
                 st_scans++;
 #endif
             };
+            unsigned long long pend = 0;  // agents with a candidate, unread bits or unread ring words
             for (;;) {
                 STAMP(t_s0);
-                // ---- SCAN: chunks as long as every lane has the ring slot free and enough lanes are idle ----
+                // ---- SCAN: chunks as long as every agent has the ring slot free and enough agents are idle ----
                 while (head < nch) {
                     const unsigned int slot = (unsigned int)head & (RING - 1);
-                    const bool room = ((nz >> slot) & 1u) == 0u;
-                    const bool idle = live && !has && word == 0u && nz == 0u;
-                    if (!__all(room) || __popcll(__ballot(idle)) < trig) break;
+                    if (__ballot((dr.nz >> slot) & 1u) != 0ull || __popcll(agents & ~pend) < trig) break;
                     if (head & 1) scan_chunk(pre_b);
                     else scan_chunk(pre_a);
+                    pend = __ballot(dr.pending()) & agents;
                 }
                 STAMP(t_s1);
 #ifdef GD_STAMPS
                 st_scan += t_s1 - t_s0;
 #endif
-                if (!__any(has || word != 0u || nz != 0u)) break;  // nothing pending anywhere; then head == nch
+                if (pend == 0ull) break;  // nothing pending anywhere; then head == nch
                 // ---- one DRAIN round ----
-#ifdef GD_STAMPS
-                {
-                    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    st_wround += __builtin_amdgcn_s_memtime() - t0;
-                }
-#endif
-                // next candidate: oldest unread ring word if the current one is used up, its lowest bit
-                const bool refill = word == 0u && nz != 0u;
-                const unsigned int rot = (nz | (nz << RING)) >> ((unsigned int)head & (RING - 1));  // bit j: chunk head - RING + j
-                const int c_new = head - RING + (__ffs(rot) - 1);
-                const unsigned int slot_new = (unsigned int)c_new & (RING - 1);
-                const unsigned int fetched = s_ring[slot_new * LW + lane];
-                word = refill ? fetched : word;
-                cw = refill ? c_new : cw;
-                nz = refill ? nz & ~(1u << slot_new) : nz;
-                const bool has_n = word != 0u;
-                const int r_nxt = K + cw * C + (__ffs(word) - 1);
-                word &= word - 1u;
-                const float2 xy_nxt = rxy[has_n ? r_nxt : 0];
-                // current candidate: exact key, live test, replay
-                const float key = ego_dist2(ex, ey, iw, iz, xy_cur.x, xy_cur.y);
-                heap.replace_top(has && key < qk[0], key, (unsigned int)r_cur, qk, qi, lk, li);
-                has = has_n;
-                r_cur = r_nxt;
-                xy_cur = xy_nxt;
+                drain_round(heap, top, dr, s_ring + col, rxy, head, ex, ey, iw, iz, owner);
+                pend = __ballot(dr.pending()) & agents;
 #ifdef GD_STAMPS
                 st_drain += __builtin_amdgcn_s_memtime() - t_s1;
                 st_rounds++;
 #endif
             }
-            heap.store_last(lk, li);
+            if (owner) heap.store(top);
         }
+        wave_sync();
         STAMP(t_f0);
-        if (live) count = heap.radius_filter(min(R, K), d.radius_key_max, s_ring + lane);
+        count = heap.radius_filter(min(R, K), d.radius_key_max, s_ring + col, owner);
 #ifdef GD_STAMPS
         st_filter = __builtin_amdgcn_s_memtime() - t_f0;
 #endif
     } else {
-        // AllEntitiesWithRadiusFiltering: first K in index order within the radius, sim.cpp:261-279
+        // AllEntitiesWithRadiusFiltering: first K in index order within the radius, sim.cpp:261-279.  Lane `sub` of an
+        // agent tests road k * G + sub of every chunk; the G partial words are OR-ed and every lane derives the
+        // positions of its own hits from the agent's word.
         const float kmax = d.radius_key_max;
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+        float pre = load_chunk(0);
+#pragma clang loop unroll(disable)
         for (int base = 0; base < R; base += C) {
-            const float2 *p = rxy + base;
-            const int tn = min(C, R - base);
-#pragma clang loop vectorize(disable) interleave(disable) unroll_count(8)
-            for (int t = 0; t < tn; t++) {
-                const float2 xy = p[t];
-                const bool pass = live && !(ego_dist2(ex, ey, iw, iz, xy.x, xy.y) > kmax);
-                if (pass && count < K) heap.i[(count + 1) * LW] = (unsigned short)(base + t);
-                count += pass ? 1 : 0;
+            const int cur = __float_as_int(pre);
+            pre = load_chunk(base + C);
+            unsigned int part = 0;
+#pragma unroll
+            for (int k = 0; k < PL; k++) {
+                const int t = k * G + sub;
+                const float2 xy = road_of(cur, k);
+                const bool pass = live && base + t < R && !(ego_dist2(ex, ey, iw, iz, xy.x, xy.y) > kmax);
+                part |= (pass ? 1u : 0u) << t;
             }
+            const unsigned int wd = agent_or(part);
+            unsigned int mine = part;
+            while (mine) {
+                const int t = __ffs(mine) - 1;
+                mine &= mine - 1u;
+                const int pos = count + __popc(wd & ((1u << t) - 1u));
+                if (pos < K) heap.i[(pos + 1) * AW] = (unsigned short)(base + t);
+            }
+            count += __popc(wd);
             if (__all(count >= K || !live)) break;
         }
     }
     // ---- hand the selection to k_map_rows ----
-    int *s_count = reinterpret_cast<int *>(s_ring);  // [LW]
+    int *s_count = reinterpret_cast<int *>(s_ring);  // [AW]
     wave_sync();
-    s_count[lane] = live ? min(count, K) : 0;
+    if (owner) s_count[col] = live ? min(count, K) : 0;
     wave_sync();
     STAMP(t_w0);
-    store_selection<A_T>(d, w, a0, min(LW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * LW + idx_col(c)]; },
-                         [&](int c) -> int { return s_count[c]; }, lane, LW);
+    store_selection<A_T>(d, w, a0, min(AW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; },
+                         [&](int c) -> int { return s_count[c]; }, lane, 64);
 #ifdef GD_STAMPS
     if (lane == 0 && blockIdx.x < 8192) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -741,9 +847,9 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4>), grid, dim3(256), 0, st, d);
         else hipLaunchKernelGGL((k_map_obs_set<128, 8>), grid, dim3(512), 0, st, d);
     } else {
-        const dim3 grid(d.W * (d.A / LW));
-        if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64>), grid, dim3(LW), 0, st, d);
-        else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(LW), 0, st, d);
+        const dim3 grid(d.W * (d.A / AW));
+        if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64>), grid, dim3(64), 0, st, d);
+        else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);
     }
     const size_t rows = (size_t)d.W * d.A * K;
     const dim3 rgrid((unsigned int)((rows + 255) / 256));

@@ -1,0 +1,6 @@
+#!/bin/bash
+# developer tool: build an alternative library gpudrive_lab_amd/expt_<name>.so with extra compiler flags
+# (e.g. tools/build_expt.sh t4 -DGD_TRIG_NUM=4); time it on the GPU box with tools/expt.sh <name> ...
+cd "$(dirname "$0")/../gpudrive_lab_amd/csrc" || exit 1
+NAME=$1; shift
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" --offload-arch=gfx950 -shared -o ../expt_$NAME.so kernels.hip map_obs.hip bev_lidar.hip pack_obs.hip episode.hip engine.cpp scene.cpp scene_cache.cpp

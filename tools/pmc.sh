@@ -25,8 +25,9 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k=row["Kernel_Name"]
-        if not any(n in k for n in ("k_map_obs","k_world_step","k_lidar","k_bev","k_pack_obs","k_episode_step")): continue
-        name=re.sub(r"\(.*","",k).replace("void gd::(anonymous namespace)::","")
+        if not any(n in k for n in ("k_map_obs","k_map_rows","k_world_step","k_lidar","k_bev","k_pack_obs","k_episode_step")): continue
+        m=re.search(r"(k_[a-z_]+(<[^>]*>)?)",k)
+        name=m.group(1) if m else k
         agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for extra in ("VGPR_Count","Accum_VGPR_Count","SGPR_Count","LDS_Block_Size","Scratch_Size","Workgroup_Size","Grid_Size"):
             if extra in row and row[extra] not in ("",None): agg[name]["_"+extra]=[float(row[extra])]

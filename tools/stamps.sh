@@ -21,7 +21,7 @@ with torch.cuda.stream(torch.cuda.Stream(device=dev)):
     torch.cuda.synchronize()
 from gpudrive_lab_amd import _capi
 lib = _capi.lib()
-n = 1024
+n = 2048
 buf = (ctypes.c_ulonglong * (8 * n))()
 rc = lib.gd_debug_read_stamps(buf, n)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.float64)
