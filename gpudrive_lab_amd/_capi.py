@@ -80,7 +80,7 @@ SYMBOLS = [
     "gd_version", "gd_last_error", "gd_default_params", "gd_tensor_shape", "gd_create", "gd_destroy",
     "gd_step", "gd_reset", "gd_set_maps", "gd_delete_agents", "gd_tensor", "gd_pack_observations",
     "gd_expert_actions", "gd_advance_log_playback", "gd_episode_step", "gd_sync",
-    "gd_set_stream",
+    "gd_set_stream", "gd_attach_bev", "gd_stat",
     "gd_kernel_timing_enable", "gd_kernel_timing_read", "gd_debug_get_state", "gd_debug_set_state",
     "gd_host_world_build", "gd_host_world_free", "gd_scene_cache_write",
 ]
@@ -133,6 +133,8 @@ def lib():
     L.gd_expert_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gd_advance_log_playback.argtypes = [C.c_void_p, C.c_int32]
     L.gd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.gd_attach_bev.argtypes = [C.c_void_p, C.c_void_p]
+    L.gd_stat.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
     L.gd_kernel_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     L.gd_kernel_timing_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.gd_debug_get_state.argtypes = [C.c_void_p, C.c_void_p]

@@ -183,6 +183,7 @@ struct gd_sim {
     // stream and replayed with a single hipGraphLaunch (the kernel arguments are the DevSim struct by
     // value, so any change of it -- rebuilt worlds, a new stream, timing mode -- drops the graph).
     hipGraphExec_t step_graph = nullptr;
+    int64_t stat_graph_steps = 0, stat_plain_steps = 0, stat_captures = 0;
     bool graph_ok = std::getenv("GPUDRIVE_NO_GRAPH") == nullptr;
 
     void drop_graph() {
@@ -195,6 +196,7 @@ struct gd_sim {
     void step() {
         if (!graph_ok || timing || stream == nullptr) {  // the legacy null stream cannot be captured
             run_rest(true);
+            stat_plain_steps++;
             return;
         }
         if (!step_graph) {
@@ -213,6 +215,7 @@ struct gd_sim {
                 throw;
             }
             HIP_CHECK(hipStreamEndCapture(stream, &g));
+            stat_captures++;
             const hipError_t e = hipGraphInstantiate(&step_graph, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (e != hipSuccess) {  // fall back to plain launches for good
@@ -223,6 +226,7 @@ struct gd_sim {
             }
         }
         HIP_CHECK(hipGraphLaunch(step_graph, stream));
+        stat_graph_steps++;
     }
 
     // setupRestOfTasks, src/sim.cpp:785-943
@@ -773,6 +777,24 @@ int gd_set_stream(gd_sim *s, void *stream) {
         s->drop_graph();
         s->stream = static_cast<hipStream_t>(stream);
     });
+}
+
+int gd_attach_bev(gd_sim *s, float *bev) {
+    if (!s || !bev) return fail(GD_ERR_INVALID, "gd_attach_bev: null argument");
+    return guarded([&]() {
+        if (s->d.bev && s->d.bev != bev) throw std::runtime_error("gd_attach_bev: a BEV tensor is already attached");
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->drop_graph();
+        s->exported[GD_T_BEV] = bev;
+        s->d.bev = bev;
+        if (!s->params.disableClassicalObs) s->launch(gd::KERNEL_BEV, false);  // the rasters of the current state
+    });
+}
+
+int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
+    if (!s || !out || which < 0 || which > 2) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
+    *out = which == 0 ? s->stat_graph_steps : which == 1 ? s->stat_plain_steps : s->stat_captures;
+    return GD_OK;
 }
 
 int gd_kernel_timing_enable(gd_sim *s, int32_t enable) {

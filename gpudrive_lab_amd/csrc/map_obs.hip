@@ -421,40 +421,61 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
 // selection lets the gather / atan2 / store work run at full occupancy instead of behind the LDS-bound selection waves.
 template <int A_T>
 __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
+    constexpr int U = 2;  // rows per thread (256 apart): two independent load chains in flight
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;  // row index over [W][A][K]
-    const size_t wa = p / K;
-    const int s = (int)(p - wa * K);
-    const int w = (int)(wa / A_T), a = (int)(wa - (size_t)w * A_T);
-    if (w >= d.W) return;
-    // everything the row needs besides the road itself is requested at once (one round trip, not a chain of them)
-    const int n = d.shape[w * 2 + 0];
-    const int cnt = d.sel_count[wa];
-    const int r0 = d.road_off[w];
-    const int sel = (int)d.sel_idx[p];
-    const float ex = d.px[wa], ey = d.py[wa], ew = d.qw[wa], ez = d.qz[wa];
-    if (a >= n) return;  // rows of padding agents are written at reset (k_init_padding_rows)
+    const size_t rows = (size_t)d.W * A_T * K;
+    const size_t p0 = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+    // everything a row needs besides the road itself is requested at once (one round trip, not a chain of them)
+    bool on[U], in[U];
+    int r[U];
+    float ex[U], ey[U], ew[U], ez[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t p = p0 + (size_t)u * 256;
+        on[u] = p < rows;
+        const size_t pc = on[u] ? p : 0;
+        const size_t wa = pc / K;
+        const int s = (int)(pc - wa * K);
+        const int w = (int)(wa / A_T), a = (int)(wa - (size_t)w * A_T);
+        const int n = d.shape[w * 2 + 0];
+        const int cnt = d.sel_count[wa];
+        r[u] = d.road_off[w] + (int)d.sel_idx[pc];
+        ex[u] = d.px[wa]; ey[u] = d.py[wa]; ew[u] = d.qw[wa]; ez[u] = d.qz[wa];
+        on[u] = on[u] && a < n;  // rows of padding agents are written at reset (k_init_padding_rows)
+        in[u] = s < cnt;
+        if (!in[u]) r[u] = d.road_off[w];
+    }
+    float2 xy[U];
+    float4 q0[U], q1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        xy[u] = d.road_xy[r[u]];
+        q0[u] = d.road_aux[(size_t)r[u] * 2];
+        q1[u] = d.road_aux[(size_t)r[u] * 2 + 1];
+    }
     // The rows are written once and not read again by the step: streaming (nt) stores keep them from pushing the
     // road and agent arrays, which every step re-reads, out of L2 / Infinity Cache.
-    float *o = d.agent_map + p * 9;
-    auto put = [&](float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8) {
-        __builtin_nontemporal_store(v0, o + 0); __builtin_nontemporal_store(v1, o + 1); __builtin_nontemporal_store(v2, o + 2);
-        __builtin_nontemporal_store(v3, o + 3); __builtin_nontemporal_store(v4, o + 4); __builtin_nontemporal_store(v5, o + 5);
-        __builtin_nontemporal_store(v6, o + 6); __builtin_nontemporal_store(v7, o + 7); __builtin_nontemporal_store(v8, o + 8);
-    };
-    if (s >= cnt) {
-        // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
-        // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
-        const float pad = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST ? 0.f : -1.f;
-        put(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (float)ET_None, pad, pad);
-        return;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (!on[u]) continue;
+        float *o = d.agent_map + (p0 + (size_t)u * 256) * 9;
+        auto put = [&](float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8) {
+            __builtin_nontemporal_store(v0, o + 0); __builtin_nontemporal_store(v1, o + 1); __builtin_nontemporal_store(v2, o + 2);
+            __builtin_nontemporal_store(v3, o + 3); __builtin_nontemporal_store(v4, o + 4); __builtin_nontemporal_store(v5, o + 5);
+            __builtin_nontemporal_store(v6, o + 6); __builtin_nontemporal_store(v7, o + 7); __builtin_nontemporal_store(v8, o + 8);
+        };
+        if (!in[u]) {
+            // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
+            // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
+            const float pad = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST ? 0.f : -1.f;
+            put(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (float)ET_None, pad, pad);
+            continue;
+        }
+        const Quat einv = quat_inv(quat_from_wz(ew[u], ez[u]));
+        const V2 rel = ego_relative(ex[u], ey[u], einv, xy[u].x, xy[u].y);
+        put(rel.x, rel.y, q0[u].z, q0[u].w, q1[u].x, quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0[u].x, q0[u].y))), q1[u].y, q1[u].z,
+            q1[u].w);
     }
-    const int r = r0 + sel;
-    const float2 xy = d.road_xy[r];
-    const float4 q0 = d.road_aux[(size_t)r * 2], q1 = d.road_aux[(size_t)r * 2 + 1];
-    const Quat einv = quat_inv(quat_from_wz(ew, ez));
-    const V2 rel = ego_relative(ex, ey, einv, xy.x, xy.y);
-    put(rel.x, rel.y, q0.z, q0.w, q1.x, quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0.x, q0.y))), q1.y, q1.z, q1.w);
 }
 
 // Selection hand-over from a workgroup that holds agents a0 .. a0+na-1 of world w as columns: idx_of(col, s) is the road
@@ -852,7 +873,7 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);
     }
     const size_t rows = (size_t)d.W * d.A * K;
-    const dim3 rgrid((unsigned int)((rows + 255) / 256));
+    const dim3 rgrid((unsigned int)((rows + 511) / 512));  // two rows per thread
     if (d.A == 64) hipLaunchKernelGGL((k_map_rows<64>), rgrid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((k_map_rows<128>), rgrid, dim3(256), 0, st, d);
 }

@@ -18,6 +18,7 @@
 #include <stdexcept>
 #include <type_traits>
 
+#include "gd_math.hpp"
 #include "scene.hpp"
 
 namespace gd {
@@ -113,20 +114,29 @@ std::shared_ptr<const SceneMap> read_scene_cache(const std::string &path, float 
         throw std::runtime_error("scene cache has impossible counts: " + path);
     const size_t off_roads = sizeof(CacheHeader) + static_cast<size_t>(h.n_objects) * sizeof(SceneObject);
     const size_t off_pts = off_roads + static_cast<size_t>(h.n_roads) * sizeof(RoadEntry);
-    if (off_pts + h.n_points * 2 * sizeof(float) != size) throw std::runtime_error("scene cache is truncated: " + path);
+    // bound n_points by what the file can hold BEFORE multiplying (a huge value must not wrap the size check)
+    if (off_pts > size || h.n_points > (size - off_pts) / (2 * sizeof(float)) || off_pts + h.n_points * 2 * sizeof(float) != size)
+        throw std::runtime_error("scene cache is truncated: " + path);
     auto map = std::make_shared<SceneMap>();
     map->mean[0] = h.mean[0]; map->mean[1] = h.mean[1];
     std::memcpy(map->name, h.name, 32);
     std::memcpy(map->scenario_id, h.scenario_id, 32);
     map->objects.resize(h.n_objects);
     if (h.n_objects) std::memcpy(map->objects.data(), base + sizeof(CacheHeader), static_cast<size_t>(h.n_objects) * sizeof(SceneObject));
+    // the object blobs are raw structs: refuse values the world builder would index arrays with
+    for (const SceneObject &o : map->objects) {
+        const bool type_ok = o.type == ET_None || o.type == ET_Vehicle || o.type == ET_Pedestrian || o.type == ET_Cyclist;
+        if (o.num_positions < 0 || o.num_positions > kMaxPositions || !type_ok)
+            throw std::runtime_error("scene cache holds a corrupt object record: " + path);
+    }
     map->roads.resize(h.n_roads);
     const float *pts = reinterpret_cast<const float *>(base + off_pts);
     uint64_t used = 0;
     for (uint32_t i = 0; i < h.n_roads; i++) {
         RoadEntry e;
         std::memcpy(&e, base + off_roads + static_cast<size_t>(i) * sizeof(RoadEntry), sizeof(e));
-        if (used + e.n_points > h.n_points) throw std::runtime_error("scene cache road table is inconsistent: " + path);
+        if (e.n_points > static_cast<uint32_t>(kMaxGeometry) || used + e.n_points > h.n_points)
+            throw std::runtime_error("scene cache road table is inconsistent: " + path);
         SceneRoad &r = map->roads[i];
         r.type = e.type; r.id = e.id; r.map_type = e.map_type;
         r.pts.assign(pts + used * 2, pts + (used + e.n_points) * 2);

@@ -1,0 +1,165 @@
+"""Torch-only mirror of the call sequence the reference's gym wrapper drives the simulator with
+(last row): `GPUDriveTorchEnv.step_dynamics -> get_rewards -> get_dones -> get_obs`
+(reference gpudrive/env/env_torch.py:606-613, 453-505, 897-945), starting from discrete action INDICES that go
+through the action table (`_set_discrete_action_space`, :666-724) and the in-place `[:, :, :3].copy_()` write
+into the exported action tensor (`_copy_actions_to_simulator`, :645-664).
+
+The reference wrapper itself keeps working on top of the drop-in `madrona_gpudrive` module; this class exists
+because it cannot be imported where `gymnasium` / `pufferlib` are missing (the GPU box), and the boundary still
+has to be exercised exactly the way the wrapper exercises it.  Same method names and argument meaning as the
+reference's class; nothing here computes simulator results.
+"""
+from itertools import product
+
+import torch
+
+# gpudrive/env/config.py:62-75 (classic / bicycle), :72-77 (delta_local)
+_ROUND = lambda t: torch.round(t, decimals=3)
+
+
+def default_action_values(dynamics_model):
+    if dynamics_model in ("classic", "bicycle"):
+        return (_ROUND(torch.linspace(-4.0, 4.0, 7)), _ROUND(torch.linspace(-torch.pi, torch.pi, 13)), torch.Tensor([0]))
+    if dynamics_model == "delta_local":
+        return (_ROUND(torch.linspace(-6.0, 6.0, 20)), _ROUND(torch.linspace(-6.0, 6.0, 20)),
+                _ROUND(torch.linspace(-torch.pi, torch.pi, 20)))
+    raise ValueError("Invalid dynamics model: %s" % dynamics_model)
+
+
+# gpudrive/env/constants.py:6-21
+MAX_SPEED, MAX_VEH_LEN, MAX_VEH_WIDTH = 100, 30, 15
+MIN_REL_GOAL_COORD, MAX_REL_GOAL_COORD = -1000, 1000
+MIN_REL_AGENT_POS, MAX_REL_AGENT_POS = -1000, 1000
+MAX_ORIENTATION_RAD = 2 * torch.pi
+MIN_RG_COORD, MAX_RG_COORD = -1000, 1000
+MAX_ROAD_LINE_SEGMENT_LEN = 100
+MAX_ROAD_SCALE = 100
+ROAD_TYPES = 7
+
+
+def _normalize_min_max(x, lo, hi):  # gpudrive/utils/geometry.py normalize_min_max
+    return 2 * ((x - lo) / (hi - lo)) - 1
+
+
+class TorchCallSequence:
+    """`sim` is a `madrona_gpudrive.SimManager`; `dynamics_model` one of "classic", "bicycle", "delta_local", "state"."""
+
+    def __init__(self, sim, dynamics_model="classic", reward_type="sparse_on_goal_achieved", norm_obs=True,
+                 action_values=None, vehicle_scale=0.7):
+        self.sim = sim
+        self.dynamics_model = dynamics_model
+        self.reward_type = reward_type
+        self.norm_obs = norm_obs
+        self.vehicle_scale = vehicle_scale
+        self.device = sim.action_tensor().to_torch().device
+        self._action_values = action_values
+        self.action_keys_tensor = None
+        if dynamics_model != "state":
+            self._set_discrete_action_space()
+        done = sim.done_tensor().to_torch()
+        self.num_worlds, self.max_agent_count = done.shape[0], done.shape[1]
+        self.world_time_steps = torch.zeros(self.num_worlds, dtype=torch.short, device=self.device)
+
+    # ---- actions: env_torch.py:666-724, 615-664 ----
+    def _set_discrete_action_space(self):
+        a1, a2, a3 = self._action_values or default_action_values(self.dynamics_model)
+        self.action_key_to_values = {}
+        self.values_to_action_key = {}
+        for action_idx, (v1, v2, v3) in enumerate(product(a1, a2, a3)):
+            self.action_key_to_values[action_idx] = [v1.item(), v2.item(), v3.item()]
+            self.values_to_action_key[round(v1.item(), 5), round(v2.item(), 5), round(v3.item(), 5)] = action_idx
+        self.action_keys_tensor = torch.tensor(
+            [self.action_key_to_values[key] for key in sorted(self.action_key_to_values.keys())]).to(self.device)
+        return len(self.action_key_to_values)
+
+    def _apply_actions(self, actions):
+        if self.dynamics_model in ("classic", "bicycle", "delta_local"):
+            if actions.dim() == 2:  # (num_worlds, max_agent_count): indices
+                actions = torch.nan_to_num(actions, nan=0).long().to(self.device)
+                action_value_tensor = self.action_keys_tensor[actions]
+            elif actions.dim() == 3:
+                if actions.shape[2] == 1:
+                    actions = actions.squeeze(dim=2).to(self.device)
+                    action_value_tensor = self.action_keys_tensor[actions]
+                else:  # the actual action values
+                    action_value_tensor = actions.to(self.device)
+            else:
+                raise ValueError(f"Invalid action shape: {actions.shape}")
+        else:
+            action_value_tensor = actions.to(self.device)
+        self._copy_actions_to_simulator(action_value_tensor)
+
+    def _copy_actions_to_simulator(self, actions):
+        if self.dynamics_model in ("classic", "bicycle", "delta_local"):
+            self.sim.action_tensor().to_torch()[:, :, :3].copy_(actions)
+        elif self.dynamics_model == "state":
+            self.sim.action_tensor().to_torch()[:, :, :10].copy_(actions)
+        else:
+            raise ValueError(f"Invalid dynamics model: {self.dynamics_model}")
+
+    # ---- step: env_torch.py:606-613 ----
+    def step_dynamics(self, actions):
+        if actions is not None:
+            self._apply_actions(actions)
+        self.sim.step()
+        not_done_worlds = ~self.get_dones().any(dim=1)
+        self.world_time_steps[not_done_worlds] += 1
+
+    # ---- results: env_torch.py:453-505 ----
+    def get_dones(self):
+        return self.sim.done_tensor().to_torch().clone().squeeze(dim=2).to(torch.float)
+
+    def get_rewards(self, collision_weight=-0.5, goal_achieved_weight=1.0, off_road_weight=-0.5):
+        info_tensor = self.sim.info_tensor().to_torch().clone()
+        off_road = info_tensor[:, :, 0].to(torch.float)
+        collided = info_tensor[:, :, 1:3].to(torch.float).sum(axis=2)
+        goal_achieved = info_tensor[:, :, 3].to(torch.float)
+        if self.reward_type == "sparse_on_goal_achieved":
+            return self.sim.reward_tensor().to_torch().clone().squeeze(dim=2)
+        if self.reward_type == "weighted_combination":
+            return collision_weight * collided + goal_achieved_weight * goal_achieved + off_road_weight * off_road
+        raise ValueError("reward_type %r is outside the harness" % self.reward_type)
+
+    # ---- observation: env_torch.py:756-896, 897-945; gpudrive/datatypes/observation.py, roadgraph.py ----
+    def _get_ego_state(self):
+        so = self.sim.self_observation_tensor().to_torch().clone()
+        speed, length, width = so[:, :, 0], so[:, :, 1] * self.vehicle_scale, so[:, :, 2] * self.vehicle_scale
+        gx, gy, collided = so[:, :, 4], so[:, :, 5], so[:, :, 6]
+        if self.norm_obs:
+            speed = speed / MAX_SPEED
+            length = length / MAX_VEH_LEN
+            width = width / MAX_VEH_WIDTH
+            gx = _normalize_min_max(gx, MIN_REL_GOAL_COORD, MAX_REL_GOAL_COORD)
+            gy = _normalize_min_max(gy, MIN_REL_GOAL_COORD, MAX_REL_GOAL_COORD)
+        return torch.stack([speed, length, width, gx, gy, collided], dim=-1)
+
+    def _get_partner_obs(self):
+        po = self.sim.partner_observations_tensor().to_torch().clone()
+        speed, x, y, yaw = po[..., 0:1], po[..., 1:2], po[..., 2:3], po[..., 3:4]
+        length, width = po[..., 4:5] * self.vehicle_scale, po[..., 5:6] * self.vehicle_scale
+        self.partner_ids = po[..., 8]
+        if self.norm_obs:
+            speed = speed / MAX_SPEED
+            x = _normalize_min_max(x, MIN_REL_AGENT_POS, MAX_REL_AGENT_POS)
+            y = _normalize_min_max(y, MIN_REL_AGENT_POS, MAX_REL_AGENT_POS)
+            yaw = yaw / MAX_ORIENTATION_RAD
+            length = length / MAX_VEH_LEN
+            width = width / MAX_VEH_WIDTH
+        return torch.concat([speed, x, y, yaw, length, width], dim=-1).flatten(start_dim=2)
+
+    def _get_road_map_obs(self):
+        rm = self.sim.agent_roadmap_tensor().to_torch().clone()
+        x, y, seg_len, seg_w, seg_h, yaw = (rm[..., k] for k in range(6))
+        types = torch.nn.functional.one_hot(rm[..., 6].long(), num_classes=ROAD_TYPES)
+        if self.norm_obs:
+            x = _normalize_min_max(x, MIN_RG_COORD, MAX_RG_COORD)
+            y = _normalize_min_max(y, MIN_RG_COORD, MAX_RG_COORD)
+            seg_len = seg_len / MAX_ROAD_LINE_SEGMENT_LEN
+            seg_w = seg_w / MAX_ROAD_SCALE
+            seg_h = seg_h / MAX_ROAD_SCALE
+            yaw = yaw / MAX_ORIENTATION_RAD
+        return torch.cat([x.unsqueeze(-1), y.unsqueeze(-1), seg_len.unsqueeze(-1), seg_w.unsqueeze(-1),
+                          seg_h.unsqueeze(-1), yaw.unsqueeze(-1), types], dim=-1).flatten(start_dim=2)
+
+    def get_obs(self):
+        return torch.cat((self._get_ego_state(), self._get_partner_obs(), self._get_road_map_obs()), dim=-1)

@@ -5,8 +5,17 @@ MI355X-native engine through the C ABI of include/gpudrive_amd.h.
 Exported tensors are torch CUDA(HIP) tensors allocated here and handed to the engine as raw
 device pointers, so `.to_torch()` is a zero-copy alias of live simulator storage, like Madrona's
 exported ECS columns (reference src/mgr.cpp:158-164,198-204).  Launches go to torch's current
-stream: the reference's step() is synchronous; here stream order gives the same data order for
-every torch consumer, and `SimManager.sync()` blocks explicitly.
+stream: the reference's step() is synchronous (src/mgr.cpp:154-156); here stream order gives the same
+data order for every torch consumer on that stream, `SimManager.sync()` blocks explicitly, and
+`SimManager(..., sync=True)` or GPUDRIVE_SYNC_STEP=1 restores the reference's blocking step / reset /
+set_maps for consumers on other streams or outside torch (DLPack, JAX).
+
+Build-specific options that the reference's constructor does not have can also be given through the
+environment, so that an unchanged `gpudrive.env.base_env` (which passes none of them,
+gpudrive/env/base_env.py:176-190) reaches them: GPUDRIVE_MAX_AGENTS (64 | 128), GPUDRIVE_KNN_ORDER
+(0 reference heap order | 1 set order), GPUDRIVE_LIDAR_HALF_ANGLE (radians; unset = the reference's
+pi/3), GPUDRIVE_SYNC_STEP (1 = blocking).  The BEV tensor needs no option: it is created on the first
+`bev_observation_tensor()` call.
 """
 import ctypes as C
 import enum
@@ -174,8 +183,16 @@ class SimManager:
 
     def __init__(self, exec_mode, gpu_id, scenes, params, enable_batch_renderer=False,
                  batch_render_view_width=64, batch_render_view_height=64, max_agents=None,
-                 knn_order=0, enable_bev=False, lidar_half_angle=0.0):
+                 knn_order=None, enable_bev=False, lidar_half_angle=None, sync=None):
         import torch
+
+        if knn_order is None:
+            knn_order = int(os.environ.get("GPUDRIVE_KNN_ORDER", "0"))
+        if lidar_half_angle is None:
+            lidar_half_angle = float(os.environ.get("GPUDRIVE_LIDAR_HALF_ANGLE", "0"))
+        if sync is None:
+            sync = os.environ.get("GPUDRIVE_SYNC_STEP", "0") not in ("", "0")
+        self._sync = bool(sync)
 
         if int(exec_mode) != int(ExecMode.CUDA):
             raise RuntimeError(
@@ -219,7 +236,10 @@ class SimManager:
             cparams = params._to_c()
             h = C.c_void_p()
             _capi.check(self._L.gd_create(C.byref(cfg), C.byref(cparams), arr, C.byref(h)), "gd_create")
+            self._stream = cfg.stream  # the stream the engine launches on until _bind_stream() sees another one
         self._h = h
+        if self._sync:
+            self.sync()
 
     # ---- lifetime ----
     def close(self):
@@ -234,17 +254,23 @@ class SimManager:
             pass
 
     def _bind_stream(self):
+        """Launch on torch's current stream.  A change of stream drains the old one first (gd_set_stream), so work
+        already queued there is ordered before everything launched from now on."""
         import torch
         st = torch.cuda.current_stream(self._device).cuda_stream
-        if st != getattr(self, "_stream", None):
-            if hasattr(self, "_stream"):
-                _capi.check(self._L.gd_set_stream(self._h, st), "gd_set_stream")
+        if st != self._stream:
+            _capi.check(self._L.gd_set_stream(self._h, st), "gd_set_stream")
             self._stream = st
+
+    def _after(self):
+        if self._sync:  # reference semantics: the call returns after the task graph has finished (src/mgr.cpp:154-156)
+            _capi.check(self._L.gd_sync(self._h), "gd_sync")
 
     # ---- control: reference src/mgr.cpp:569-588 ----
     def step(self):
         self._bind_stream()
         _capi.check(self._L.gd_step(self._h), "gd_step")
+        self._after()
 
     def reset(self, worlds):
         """Accepts an int (gpudrive sb3_wrapper.py:163), a list, a numpy array (env_puffer.py:376)
@@ -255,12 +281,14 @@ class SimManager:
         idx = np.ascontiguousarray(idx)
         self._bind_stream()
         _capi.check(self._L.gd_reset(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx)), "gd_reset")
+        self._after()
 
     def set_maps(self, maps):
         maps = [os.fspath(m) for m in maps]
         self._bind_stream()
         arr = (C.c_char_p * len(maps))(*[m.encode("utf-8") for m in maps])
         _capi.check(self._L.gd_set_maps(self._h, arr, len(maps)), "gd_set_maps")
+        self._after()
 
     def deleteAgents(self, agents_to_delete):
         worlds, offsets, ids = [], [0], []
@@ -275,6 +303,7 @@ class SimManager:
         P = C.POINTER(C.c_int32)
         _capi.check(self._L.gd_delete_agents(self._h, wa.ctypes.data_as(P), oa.ctypes.data_as(P),
                                              ia.ctypes.data_as(P), len(worlds)), "gd_delete_agents")
+        self._after()
 
     def sync(self):
         _capi.check(self._L.gd_sync(self._h), "gd_sync")
@@ -317,10 +346,24 @@ class SimManager:
 
     # ---- dead / out-of-scope API kept for attribute compatibility ----
     def bev_observation_tensor(self):
-        """[W, A, 200, 200, 1] f32.  The reference always rasterises the BEV (160 KB per agent, 10.5 GB
-        at 1024 x 64); here it is computed only when the sim was built with enable_bev=True."""
-        if not self._enable_bev:
-            raise NotImplementedError("bev_observation_tensor: construct SimManager(..., enable_bev=True)")
+        """[W, A, 200, 200, 1] f32 (reference src/mgr.cpp:870-880).  The reference rasterises the BEV of every agent
+        on every step whether anyone reads it or not (160 KB per agent, 10.5 GB at 1024 x 64).  Here the
+        tensor is created by the first call (or by enable_bev=True at construction): that call computes the rasters of
+        the current state, and from then on every step / reset refreshes them like the reference does, so the
+        unchanged caller (gpudrive/env/env_torch.py:926-945) sees the same data."""
+        import torch
+        if _capi.T_BEV not in self._tensors:
+            desc = _capi.GdTensorDesc()
+            _capi.check(self._L.gd_tensor_shape(_capi.T_BEV, self._W, self._A, C.byref(desc)), "gd_tensor_shape")
+            dims = [int(desc.dims[i]) for i in range(desc.ndim)]
+            with torch.cuda.device(self._device):
+                t = torch.zeros(dims, dtype=torch.float32, device=self._device)
+                torch.cuda.current_stream(self._device).synchronize()
+                self._bind_stream()
+                _capi.check(self._L.gd_attach_bev(self._h, t.data_ptr()), "gd_attach_bev")
+            self._tensors[_capi.T_BEV] = t
+            self._enable_bev = True
+            self._after()
         return Tensor(self._tensors[_capi.T_BEV])
 
     def valid_state_tensor(self):
@@ -333,6 +376,12 @@ class SimManager:
         raise NotImplementedError("depth_tensor: the Madrona batch renderer is outside this engine's scope")
 
     # ---- engine hooks used by bench.py / tests ----
+    def stat(self, which):
+        """0 = steps replayed from the captured hipGraph, 1 = steps launched kernel by kernel, 2 = graph captures."""
+        out = C.c_int64()
+        _capi.check(self._L.gd_stat(self._h, int(which), C.byref(out)), "gd_stat")
+        return out.value
+
     def kernel_timing(self, enable):
         _capi.check(self._L.gd_kernel_timing_enable(self._h, int(bool(enable))))
 

@@ -206,6 +206,14 @@ int gd_episode_step(gd_sim *sim, const gd_episode_config *cfg, const gd_episode_
 int gd_sync(gd_sim *sim);
 /* Change the launch stream (e.g. torch's current stream). */
 int gd_set_stream(gd_sim *sim, void *stream);
+/* Attach the BEV tensor after construction (replaces the reference's always-on BevObservations export,
+ * src/mgr.cpp:870-880 + src/sim.cpp:462-555: there the raster exists from the start; here it is created on the first
+ * bev_observation_tensor() call).  `bev` is a device buffer of gd_tensor_shape(GD_T_BEV) floats that the
+ * caller keeps alive.  The rasters of the current state are computed at once; every later step / reset refreshes them. */
+int gd_attach_bev(gd_sim *sim, float *bev);
+/* Engine counters (tests and diagnostics).  which: 0 = steps replayed from the captured hipGraph,
+ * 1 = steps launched kernel by kernel, 2 = hipGraph captures. */
+int gd_stat(gd_sim *sim, int32_t which, int64_t *out);
 
 /* Timing hooks for the bench: HIP events around the named kernel on the engine's stream.
  * kernel: 0 = state step, 1 = road observation, 2 = LiDAR, 3 = BEV. */

@@ -1308,6 +1308,20 @@ void *orc_tensor(orc_sim *s, int id) {
 
 int64_t orc_knn_inserts(orc_sim *s) { return s->knn_inserts; }
 
+/* Test hook: observationOf of EVERY road of world w in agent a's frame, in road order (the sequence
+ * selectKNearestRoadEntities consumes, knn.hpp:112-136), 9 floats per road.  tests/test_heap_pin.py feeds the keys
+ * of these rows to an independent program built on libstdc++'s heap functions. */
+int orc_debug_road_obs(orc_sim *s, int w, int a, float *out) {
+    World *wd = &s->worlds[w];
+    AgentEnt *ag = &wd->agents[a];
+    RefFrame rf = { { ag->pos.x, ag->pos.y }, ag->rot };
+    for (int r = 0; r < wd->num_roads; r++) {
+        MapObs m = road_obs(&rf, &wd->roads[r]);
+        memcpy(out + (size_t)r * 9, &m, sizeof(m));
+    }
+    return wd->num_roads;
+}
+
 /* Test hooks for teacher forcing: read / overwrite the internal agent state
  * layout per agent: pos(3) quat wxyz(4) vel_lin(3) collided(1) = 11 floats */
 void orc_get_state(orc_sim *s, float *out) {

@@ -92,6 +92,8 @@ def lib(path=None):
     L.orc_knn_inserts.restype = C.c_int64
     L.orc_knn_inserts.argtypes = [C.c_void_p]
     L.orc_get_state.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_debug_road_obs.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.orc_debug_road_obs.restype = C.c_int32
     L.orc_set_state.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_test_obb_collide.restype = C.c_int
     L.orc_test_obb_collide.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
@@ -295,6 +297,12 @@ class OracleSim:
         for t in range(init_steps):
             self.action_tensor()[:, :, :cols] = act[:, :, t, :]
             self.step()
+
+    def road_obs_of(self, w, a):
+        """observationOf of every road of world w in agent a's frame, in road order: [R, 9]."""
+        out = np.zeros((MAX_ROADS, 9), np.float32)
+        n = self.L.orc_debug_road_obs(self.h, int(w), int(a), out.ctypes.data)
+        return out[:n].copy()
 
     def knn_inserts(self):
         return int(self.L.orc_knn_inserts(self.h))

@@ -26,7 +26,7 @@ PARAM_KEYS = ("polylineReductionThreshold", "observationRadius", "rewardType", "
 ORACLE_ONLY_KEYS = ("enableBev", "lidarHalfAngle")
 
 
-def make_gpu_sim(scenes, max_agents=64, knn_order=0, enable_bev=False, lidar_half_angle=0.0, **kw):
+def make_gpu_sim(scenes, max_agents=64, knn_order=0, enable_bev=False, lidar_half_angle=0.0, sync=None, **kw):
     import madrona_gpudrive as mg
     p = mg.Parameters()
     for k, v in kw.items():
@@ -37,7 +37,7 @@ def make_gpu_sim(scenes, max_agents=64, knn_order=0, enable_bev=False, lidar_hal
             setattr(p, k, v)
     return mg.SimManager(exec_mode=mg.madrona.ExecMode.CUDA, gpu_id=0, scenes=list(scenes), params=p,
                          max_agents=max_agents, knn_order=knn_order, enable_bev=enable_bev,
-                         lidar_half_angle=lidar_half_angle)
+                         lidar_half_angle=lidar_half_angle, sync=sync)
 
 
 def make_oracle_sim(O, scenes, max_agents=64, **kw):

@@ -137,6 +137,56 @@ def check_road_selection_by_brute_force(sim, radius, as_numpy=np.array, K=200, m
     return checked
 
 
+def check_partner_rows_by_brute_force(sim, radius, as_numpy=np.array, margin=1e-3, atol=2e-4):
+    """collectPartnerObsSystem (reference src/sim.cpp:188-240) recomputed in float64 numpy from the ABSOLUTE rows,
+    independently of the oracle: slot k of ego i is agent j = k-th other agent in index order; within the radius
+    the row is {j's speed, ego-frame position, relative heading, j's size, j's type, j's id}, beyond it the
+    all-zero row with id -1 (a pair within `margin` of the radius may go either way), and slots >= n - 1 are the
+    all-zero row with id -2."""
+    ab = as_numpy(sim.absolute_self_observation_tensor()).astype(np.float64)
+    so = as_numpy(sim.self_observation_tensor()).astype(np.float64)
+    po = as_numpy(sim.partner_observations_tensor()).astype(np.float64)
+    info = as_numpy(sim.info_tensor())
+    shape = as_numpy(sim.shape_tensor())
+    A, C, P = COL.ABS_OBS, COL.SELF_OBS, COL.PARTNER_OBS
+    zero_row = np.zeros(9)
+    n_in = n_out = 0
+    for w in range(ab.shape[0]):
+        n = int(shape[w, 0])
+        pos = ab[w, :n][:, [A["pos_x"], A["pos_y"]]]
+        yaw = ab[w, :n, A["rotation_angle"]]
+        size = ab[w, :n][:, [A["vehicle_length"], A["vehicle_width"], A["vehicle_height"]]]
+        for i in range(n):
+            c, s_ = np.cos(yaw[i]), np.sin(yaw[i])
+            others = [j for j in range(n) if j != i]
+            for k, j in enumerate(others):
+                d = pos[j] - pos[i]
+                rel = np.array([c * d[0] + s_ * d[1], -s_ * d[0] + c * d[1]])
+                dist = np.hypot(*rel)
+                row = po[w, i, k]
+                if row[P["ids"]] == -1:  # zero(): claimed to be beyond the radius
+                    assert dist > radius - margin, (w, i, j, dist)
+                    z = zero_row.copy(); z[P["ids"]] = -1
+                    assert np.array_equal(row, z), (w, i, j, row)
+                    n_out += 1
+                    continue
+                assert dist <= radius + margin, (w, i, j, dist)
+                exp = np.zeros(9)
+                exp[P["speed"]] = so[w, j, C["speed"]]
+                exp[[P["rel_pos_x"], P["rel_pos_y"]]] = rel
+                exp[P["orientation"]] = row[P["orientation"]]  # compared modulo 2 pi below
+                exp[[P["vehicle_length"], P["vehicle_width"], P["vehicle_height"]]] = size[j]
+                exp[P["agent_type"]] = info[w, j, 4]
+                exp[P["ids"]] = ab[w, j, A["id"]]
+                assert np.allclose(row, exp, atol=atol, rtol=0), (w, i, j, row, exp)
+                assert abs(wrap(row[P["orientation"]] - (yaw[j] - yaw[i]))) < 1e-4
+                n_in += 1
+            tail = po[w, i, max(n - 1, 0):]
+            z = zero_row.copy(); z[P["ids"]] = -2
+            assert (tail == z).all(), (w, i, "rows beyond the last other agent must be zero_nonexist()")
+    return n_in, n_out
+
+
 def test_cross_tensor_invariants_on_the_oracle(oracle_mod):
     O = oracle_mod
     p = O.default_params(polylineReductionThreshold=0.1, observationRadius=40.0, collisionBehaviour=2, rewardType=1,
@@ -150,6 +200,8 @@ def test_cross_tensor_invariants_on_the_oracle(oracle_mod):
     n_pairs, n_roads = check_cross_tensor_invariants(sim)
     assert n_pairs > 500 and n_roads > 1500
     assert check_road_selection_by_brute_force(sim, 40.0) == 25 + 64
+    n_in, n_out = check_partner_rows_by_brute_force(sim, 40.0)
+    assert n_in > 500 and n_out > 500
 
 
 def test_road_selection_by_brute_force_when_K_binds(oracle_mod):

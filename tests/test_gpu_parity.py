@@ -191,8 +191,6 @@ def test_bev_parity(oracle_mod):
         orc.reset([])
         painted = P.compare_bev(gpu, orc)
         assert painted > 0.001
-    with pytest.raises(NotImplementedError):
-        P.make_gpu_sim([TEST_JSON], max_agents=64, **kw).bev_observation_tensor()
     gpu.close()
 
 
