@@ -12,8 +12,14 @@ Workload (BASELINE.json configs[1]): 1024 worlds x 64 agents per GPU, classic bi
 63-partner + 200-road-point k-NN observation, radius 50, collisions ignored.  Primary: the seeded
 synthetic exact-64 scenes of SURVEY.md section 8d (64 live agents, 4096 road segments per world).
 Secondary (reported under "other_workloads"): the committed Waymo scenes tiled round-robin.
+
+Kernel times in the line (`kernels`, `roofline.avg_kernel_us`) are HIP-event times of the SAME steps the wall clock
+brackets (events on the engine's stream around every launch), so a kernel average can be compared with `ms_per_step`
+directly.  With N > 1 ranks a second stretch measures BASELINE configs[3]'s observation all-gather (RCCL), overlapped
+with the following step (`allgather` in the line; `--gather none` skips it).
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -34,6 +40,20 @@ from gpudrive_lab_amd import sharding, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 EPISODE = 91
+
+
+
+def source_stamp():
+    """sha256 over the engine sources: profiles/*_traffic.json carries the stamp of the build its counters were
+    collected on, and `roofline.traffic` is null when it is not this build's."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gpudrive_lab_amd", "csrc")
+    for name in sorted(os.listdir(d)) + ["../../include/gpudrive_amd.h"]:
+        if name.endswith((".hip", ".cpp", ".hpp", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
 
 WAYMO = [os.path.join(ROOT, "tests", "data", n) for n in
          ("test.json", "tfrecord-00002-of-01000_407.json", "tfrecord-00000-of-01000_4.json")]
@@ -127,6 +147,9 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
         tracker = EpisodeTracker(sim)
 
     k = run_steps(sim, batches, all_worlds, args.warmup, tracker=tracker)
+    # HIP events around every kernel launch of the timed steps themselves (gd_kernel_timing_*): the per-kernel averages
+    # in the line describe the same steps as ms_per_step
+    sim.kernel_timing(True)
     sharding.barrier(device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -142,12 +165,7 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
         agent_steps_per_s=total_live * args.steps / elapsed,
         padded_agent_steps_per_s=world * args.worlds * args.agents * args.steps / elapsed,
     )
-    # dominant-kernel roofline: HIP events on the engine's stream around every launch of the road
-    # observation kernel, over a separate timed stretch (so `value` is not perturbed)
-    sim.kernel_timing(True)
-    run_steps(sim, batches, all_worlds, args.roofline_steps, start=k, tracker=tracker)
-    torch.cuda.synchronize(device)
-    names = {0: "k_world_step", 1: "k_map_obs"}
+    names = {0: "k_world_step", 1: "k_map_obs+k_map_rows"}
     if workload == "lidar":
         names[2] = "k_lidar"
     if workload == "bev":
@@ -157,27 +175,88 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
         ms, n = sim.kernel_timing_read(kid)
         kt[name] = dict(avg_us=1e3 * ms / max(n, 1), launches=n)
     sim.kernel_timing(False)
-    # algorithmic bytes per launch, SURVEY.md 8d: per world 36*R_w + 16*N_w + 7200*N_w
+    # algorithmic bytes per launch, SURVEY.md 8d: per world 36*R_w + 16*N_w + 7200*N_w (road selection + row write-out:
+    # k_map_obs hands its selection to k_map_rows; the two launches are one reference system and are timed together)
     alg_bytes = 36.0 * roads + (16.0 + 7200.0) * live
-    avg_s = kt["k_map_obs"]["avg_us"] * 1e-6
+    avg_s = kt["k_map_obs+k_map_rows"]["avg_us"] * 1e-6
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     res["kernels"] = kt
     # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command
-    # (tools/profile.sh, committed under profiles/); counters cannot be read from inside the process.
+    # (tools/profile.sh, committed under profiles/); counters cannot be read from inside the process.  The file names
+    # the source stamp of the build it was collected on; another build gets null.
     traffic = None
     try:
-        tkey = ("set_" if args.knn_order == 1 else "exact_") + workload if workload != "lidar" else "lidar"
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            traffic = json.load(fh).get(tkey, {}).get("hbm_bytes_per_launch")
-        if args.worlds != 1024 or args.agents != 64:
-            traffic = None
+        tkey = ("set_" if args.knn_order == 1 else "exact_") + workload
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+            tj = json.load(fh)
+        if tj.get("source_stamp") == source_stamp() and args.worlds == 1024 and args.agents == 64:
+            traffic = tj.get(tkey, {}).get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
-    res["roofline"] = dict(bound="hbm", kernel="k_map_obs", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+    res["roofline"] = dict(bound="hbm", kernel="k_map_obs+k_map_rows", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                            frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                           algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt["k_map_obs"]["avg_us"])
+                           algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt["k_map_obs+k_map_rows"]["avg_us"])
+    # the other kernels with a SURVEY 8d byte count, same steps
+    extra = {}
+    if "k_lidar" in kt and kt["k_lidar"]["avg_us"] > 0:
+        b = 2400.0 * live + 36.0 * roads
+        extra["k_lidar"] = dict(algorithmic_bytes_per_launch=b, achieved=b / (kt["k_lidar"]["avg_us"] * 1e-6) / 1e9,
+                                frac=b / (kt["k_lidar"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, unit="GB/s")
+    if "k_bev" in kt and kt["k_bev"]["avg_us"] > 0:
+        b = 160000.0 * live
+        extra["k_bev"] = dict(algorithmic_bytes_per_launch=b, achieved=b / (kt["k_bev"]["avg_us"] * 1e-6) / 1e9,
+                              frac=b / (kt["k_bev"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, unit="GB/s")
+    if kt["k_world_step"]["avg_us"] > 0:
+        b = (40.0 + 52.0 + 28.0 + 88.0 + 36.0 * (args.agents - 1)) * live
+        extra["k_world_step"] = dict(algorithmic_bytes_per_launch=b, achieved=b / (kt["k_world_step"]["avg_us"] * 1e-6) / 1e9,
+                                     frac=b / (kt["k_world_step"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, unit="GB/s")
+    res["other_rooflines"] = extra
+    res["engine"] = dict(graph_steps=sim.stat(0), plain_steps=sim.stat(1), graph_captures=sim.stat(2))
+    # ---- BASELINE configs[3]: observation all-gather over RCCL, overlapped with the next step ----
+    if world > 1 and args.gather != "none" and workload == args.workloads.split(",")[0]:
+        res["allgather"] = gather_stretch(sim, batches, all_worlds, args, k, device, world)
     sim.close()
     return res
+
+
+def gather_stretch(sim, batches, all_worlds, args, k, device, world):
+    """Every step: simulator step, fused observation pack, all-gather of the packed block (raw) or of the controlled
+    agents' rows (compact) on a side stream while the next step runs (sharding.ObservationGather)."""
+    import torch.distributed as dist
+    D = 6 + (args.agents - 1) * 6 + 200 * 13
+    og = sharding.ObservationGather(args.gather, args.worlds * args.agents, D, device)
+    og.set_mask(sim.controlled_state_tensor().to_torch()[..., 0] == 1)
+    act = sim.action_tensor().to_torch()
+    steps = args.gather_steps
+
+    def one(i):
+        act.copy_(batches[i % len(batches)])
+        sim.step()
+        obs = sim.packed_observations()
+        if i > k:
+            og.wait()          # the learner would consume step i-1's gathered block here
+        og.start(obs)
+    for i in range(k, k + 3):
+        one(i)
+    og.wait()
+    og.events.clear()
+    sharding.barrier(device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(k + 3, k + 3 + steps):
+        one(i)
+    full, counts = og.wait()
+    torch.cuda.synchronize(device)
+    sharding.barrier(device)
+    elapsed = sharding.reduce_max(time.perf_counter() - t0, device)
+    ms = og.mean_ms()
+    per_rank = og.bytes_per_rank
+    return dict(mode=args.gather, backend=dist.get_backend(), world_size=dist.get_world_size(), steps=steps,
+                bytes_per_rank=per_rank, rows_per_rank=int(og.cap), controlled_per_rank=[int(c) for c in counts.tolist()],
+                allgather_ms=ms, ms_per_step_with_gather=1e3 * elapsed / steps,
+                gb_per_s_per_link=(per_rank / (ms * 1e-3) / 1e9) if ms else None,
+                gathered_shape=list(full.shape),
+                note="per-link rate = one peer's block / gather time (every peer's block rides its own xGMI link)")
 
 
 def cpu_baseline(args, budget_s=15.0):
@@ -194,31 +273,42 @@ def cpu_baseline(args, budget_s=15.0):
     except Exception:
         so = None
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    worlds = max(cores * 2, 16)
     kw = params_for("synthetic")
-    scenes = scenes_for("synthetic", worlds, 0)
-    sim = O.OracleSim(scenes, O.default_params(**kw), max_agents=args.agents, lib_path=so)
-    live = int(sim.shape_tensor()[:, 0].sum())
     rng = np.random.default_rng(0)
-    act = sim.action_tensor()
 
-    def one():
-        act[..., 0] = rng.uniform(-3, 2, act.shape[:2])
-        act[..., 1] = rng.uniform(-0.7, 0.7, act.shape[:2])
-        sim.step()
-    t0 = time.perf_counter()
-    one()
-    first = time.perf_counter() - t0
-    steps = int(max(3, min(200, budget_s / max(first, 1e-4))))
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    def run(worlds, threads, budget):
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        scenes = scenes_for("synthetic", worlds, 0)
+        sim = O.OracleSim(scenes, O.default_params(**kw), max_agents=args.agents, lib_path=so)
+        if hasattr(sim.L, "orc_set_threads"):
+            sim.L.orc_set_threads(int(threads))
+        live = int(sim.shape_tensor()[:, 0].sum())
+        act = sim.action_tensor()
+
+        def one():
+            act[..., 0] = rng.uniform(-3, 2, act.shape[:2])
+            act[..., 1] = rng.uniform(-0.7, 0.7, act.shape[:2])
+            sim.step()
+        t0 = time.perf_counter()
         one()
-    dt = time.perf_counter() - t0
-    sim.close()
-    return dict(value=live * steps / dt, unit="agent-steps/s", cores=cores, kind="port",
-                sample="%d synthetic exact-64 worlds (R_w=4096) x %d steps, OpenMP over worlds, %.1f s; "
-                       "the reference's own CPU ExecMode cannot be built (Madrona submodule absent)"
-                       % (worlds, steps, dt))
+        first = time.perf_counter() - t0
+        steps = int(max(3, min(200, budget / max(first, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        dt = time.perf_counter() - t0
+        sim.close()
+        return live * steps / dt, worlds, steps, dt
+    # one world per thread (Madrona's ThreadPoolExecutor runs one world per task, src/mgr.cpp:527-535), at most 64
+    # threads: beyond that the 4096-road scan of the port is memory-bound on the host and scales no further
+    threads = max(1, min(cores, 64))
+    rate, worlds, steps, dt = run(threads, threads, budget_s * 0.7)
+    rate1, _, steps1, dt1 = run(1, 1, budget_s * 0.3)
+    return dict(value=rate, unit="agent-steps/s", cores=threads, host_cores=cores, kind="port",
+                single_thread_value=rate1,
+                sample="%d synthetic exact-64 worlds (R_w=4096) x %d steps on %d OpenMP threads (one world per thread), %.1f s; "
+                       "1 world x %d steps on 1 thread, %.1f s; the reference's own CPU ExecMode cannot be built "
+                       "(Madrona submodule absent)" % (worlds, steps, threads, dt, steps1, dt1))
 
 
 def main():
@@ -228,7 +318,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=91)
     ap.add_argument("--worlds", type=int, default=1024, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=64, choices=(64, 128))
-    ap.add_argument("--roofline-steps", type=int, default=91, help="separately timed stretch for per-kernel HIP-event timing: one whole episode")
+    ap.add_argument("--roofline-steps", type=int, default=0, help="ignored (kept for old command lines): kernels are timed over the timed steps themselves")
+    ap.add_argument("--gather", default="compact", choices=("none", "raw", "compact"),
+                    help="N > 1 only: after the timed region, a stretch with the observation all-gather of BASELINE configs[3] "
+                         "(raw = every agent slot's packed observation, compact = controlled agents only), overlapped with the next step")
+    ap.add_argument("--gather-steps", type=int, default=30)
     ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop",
                     help="first = primary; synthetic | waymo | lidar (Waymo tiles + 360-degree LiDAR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -280,10 +374,14 @@ def main():
             "padded_agent_steps_per_s": primary["padded_agent_steps_per_s"],
             "roofline": primary["roofline"],
             "kernels": primary["kernels"],
+            "kernel_times": "HIP events around every launch of the timed steps themselves (same steps as ms_per_step)",
+            "other_rooflines": primary.get("other_rooflines"),
+            "engine": dict(primary.get("engine", {}), source_stamp=source_stamp(), road_kernel_agents_per_wave=32),
+            "allgather": primary.get("allgather"),
             "cpu_baseline": cpu,
             "other_workloads": [
                 {k: r[k] for k in ("workload", "agent_steps_per_s", "padded_agent_steps_per_s", "ms_per_step",
-                                   "live_agents_per_rank", "road_entities_per_rank", "roofline", "kernels")}
+                                   "live_agents_per_rank", "road_entities_per_rank", "roofline", "kernels", "other_rooflines")}
                 for r in results[1:]],
             "init_seconds": primary["init_seconds"],
         }

@@ -77,6 +77,108 @@ def reduce_sum(value, device):
     return float(t.item())
 
 
+class ObservationGather:
+    """Config 4 (BASELINE.json): the learner-side observation of every rank's worlds on every rank, gathered while
+    the next step runs.
+
+    `mode` "raw": the rank's whole block [W_local, A, D].  "compact": only the rows of controlled agents (the rows
+    a learner consumes, gpudrive/env/env_puffer.py:169-176), packed to the front of a [cap, D] buffer; `cap` is the
+    largest controlled-agent count over the ranks (one all-reduce at set-up), so every rank contributes an equal block
+    and each peer's shard rides its own xGMI link (direct gather, not a ring).  The controlled mask is
+    fixed between world rebuilds, so the row index is computed once (`set_mask`).
+
+    `start(block)` copies / compacts `block` into a send buffer on the caller's stream and launches the all-gather on
+    a side stream; `wait()` makes the caller's stream wait for it and returns (gathered [world * cap, D], counts
+    [world]) -- rows beyond counts[r] in rank r's section are stale padding.  Two send / receive buffers alternate, so
+    the gather of step k overlaps step k + 1.  On CPU tensors (gloo, tests) everything runs inline."""
+
+    def __init__(self, mode, world_agents, feature_dim, device, dtype=torch.float32):
+        assert mode in ("raw", "compact")
+        self.mode, self.device, self.dim = mode, torch.device(device), int(feature_dim)
+        self.rows = int(world_agents)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.cuda = self.device.type == "cuda"
+        self.nccl = dist.is_initialized() and dist.get_backend() == "nccl" and self.cuda
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.index, self.count, self.cap = None, self.rows, self.rows
+        self.counts = torch.full((self.world,), self.rows, dtype=torch.int64)
+        self._dtype = dtype
+        self._alloc()
+        self._k, self._pending = 0, None
+        self.events = []  # (start, stop) cuda events of every launched gather, for timing
+
+    def _alloc(self):
+        mk = lambda n: torch.empty((n, self.dim), dtype=self._dtype, device=self.device)
+        self.send = [mk(self.cap), mk(self.cap)]
+        self.recv = [mk(self.world * self.cap), mk(self.world * self.cap)]
+
+    def set_mask(self, controlled):
+        """controlled: bool / int tensor [W_local, A] (controlled_state_tensor).  Compact mode only."""
+        if self.mode != "compact":
+            return
+        flat = controlled.reshape(-1).to(torch.bool)
+        self.index = torch.nonzero(flat, as_tuple=False).reshape(-1).to(self.device)
+        self.count = int(self.index.numel())
+        c = torch.tensor([self.count], dtype=torch.int64, device=_collective_device(self.device if self.nccl else None))
+        if dist.is_initialized():
+            lst = [torch.zeros_like(c) for _ in range(self.world)]
+            dist.all_gather(lst, c)
+            self.counts = torch.cat([t.cpu() for t in lst])
+        else:
+            self.counts = c.cpu()
+        self.cap = max(int(self.counts.max().item()), 1)
+        self._alloc()
+
+    @property
+    def bytes_per_rank(self):
+        return self.cap * self.dim * self.send[0].element_size()
+
+    def start(self, block):
+        k = self._k
+        self._k ^= 1
+        src = block.reshape(-1, self.dim)
+        if self.mode == "compact":
+            torch.index_select(src, 0, self.index, out=self.send[k][:self.count])
+        else:
+            self.send[k].copy_(src)
+        if not dist.is_initialized():
+            self._pending = (k, None)
+            self.recv[k][:self.cap].copy_(self.send[k])
+            return
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(self.stream)
+                if self.nccl:
+                    dist.all_gather_into_tensor(self.recv[k], self.send[k])
+                else:  # gloo rehearsal on one GPU: through host memory
+                    host = torch.empty((self.world * self.cap, self.dim), dtype=self._dtype)
+                    dist.all_gather_into_tensor(host, self.send[k].cpu())
+                    self.recv[k].copy_(host)
+                ev1.record(self.stream)
+                self.events.append((ev0, ev1))
+            self._pending = (k, ev1)
+        else:
+            dist.all_gather_into_tensor(self.recv[k], self.send[k])
+            self._pending = (k, None)
+
+    def wait(self):
+        k, ev = self._pending
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return self.recv[k], self.counts
+
+    def mean_ms(self):
+        if not self.events:
+            return None
+        self.events[-1][1].synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+
 def gather_observations(local, out=None):
     """All-gather a rank's observation block [W_local, ...] into [world * W_local, ...] on every
     rank (equal W_local per rank).  `out` may be a preallocated buffer reused across steps."""

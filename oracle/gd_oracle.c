@@ -28,6 +28,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define K_MAP 200            /* src/consts.hpp:13 kMaxAgentMapObservationsCount */
 #define MAX_ROADS_ENT 10000  /* src/consts.hpp:12 kMaxRoadEntityCount */
@@ -1307,6 +1310,17 @@ void *orc_tensor(orc_sim *s, int id) {
 }
 
 int64_t orc_knn_inserts(orc_sim *s) { return s->knn_inserts; }
+
+/* bench.py cpu_baseline: worker threads of the one-world-per-task loops (0 = leave the OpenMP default) */
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* Test hook: observationOf of EVERY road of world w in agent a's frame, in road order (the sequence
  * selectKNearestRoadEntities consumes, knn.hpp:112-136), 9 floats per road.  tests/test_heap_pin.py feeds the keys

@@ -92,6 +92,8 @@ def lib(path=None):
     L.orc_knn_inserts.restype = C.c_int64
     L.orc_knn_inserts.argtypes = [C.c_void_p]
     L.orc_get_state.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_set_threads.argtypes = [C.c_int32]
+    L.orc_set_threads.restype = C.c_int32
     L.orc_debug_road_obs.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.orc_debug_road_obs.restype = C.c_int32
     L.orc_set_state.argtypes = [C.c_void_p, C.c_void_p]

@@ -51,6 +51,33 @@ _WORKER = textwrap.dedent("""
     # preallocated output buffer is reused
     out = torch.empty(6, 4, 5)
     assert sharding.gather_observations(local, out).data_ptr() == out.data_ptr()
+    # config 4: the packed observation [W_local, A, D] of the real shape (A = 64: D = 6 + 63 * 6 + 200 * 13), raw and
+    # controlled-agent-compacted, double-buffered; rank r's rows must land in section r, in agent order
+    W, A, D = 3, 64, 6 + 63 * 6 + 200 * 13
+    g = torch.Generator().manual_seed(100 + rank)
+    obs = torch.rand(W, A, D, generator=g)
+    ctrl = torch.rand(W, A, generator=g) < (0.3 if rank == 0 else 0.6)   # unequal counts across ranks
+    peer = torch.Generator().manual_seed(100 + (1 - rank))
+    peer_obs = torch.rand(W, A, D, generator=peer)
+    peer_ctrl = torch.rand(W, A, generator=peer) < (0.3 if rank == 1 else 0.6)
+    both = {rank: (obs, ctrl), 1 - rank: (peer_obs, peer_ctrl)}
+    raw = sharding.ObservationGather("raw", W * A, D, dev)
+    raw.start(obs)
+    full, counts = raw.wait()
+    assert full.shape == (2 * W * A, D) and counts.tolist() == [W * A, W * A] and raw.bytes_per_rank == W * A * D * 4
+    for r in range(2):
+        assert torch.equal(full[r * W * A:(r + 1) * W * A], both[r][0].reshape(-1, D))
+    cg = sharding.ObservationGather("compact", W * A, D, dev)
+    cg.set_mask(ctrl)
+    n = [int(both[r][1].sum()) for r in range(2)]
+    assert cg.counts.tolist() == n and cg.cap == max(n)
+    for step in range(3):   # the two buffers alternate
+        cg.start(obs + step)
+        full, counts = cg.wait()
+        assert full.shape == (2 * cg.cap, D)
+        for r in range(2):
+            exp = (both[r][0] + step).reshape(-1, D)[both[r][1].reshape(-1)]
+            assert torch.equal(full[r * cg.cap:r * cg.cap + n[r]], exp), (step, r)
     torch.distributed.destroy_process_group()
     print("rank", rank, "ok")
 """)

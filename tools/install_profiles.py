@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
 """Copy the summaries that tools/profile_all.sh left under gpurun_out/prof_<tag>/ into profiles/
-(r01_<tag>_kernel_stats.csv, r01_<tag>_bench_under_rocprof.json, r01_<tag>_pmc_traffic.json) and
-rebuild profiles/r01_traffic.json, the per-launch HBM bytes bench.py reports as roofline.traffic:
-(2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 HBM note)."""
+(<round>_<tag>_kernel_stats.csv, _bench_under_rocprof.json, _pmc_traffic.json, _pmc_sq.json, _occupancy.json) and rebuild
+profiles/<round>_traffic.json, the per-launch HBM bytes bench.py reports as roofline.traffic:
+(2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 HBM note).  The road observation is
+two launches (k_map_obs or k_map_obs_set, then k_map_rows); their bytes are summed.  The file is stamped with the source
+hash of the build (bench.source_stamp): bench.py reports the traffic only for that build."""
 import json
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
-TAGS = ("exact_synthetic", "exact_waymo", "set_synthetic", "set_waymo", "lidar")
-traffic = {}
+sys.path.insert(0, ROOT)
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAGS = ("exact_synthetic", "exact_waymo", "set_synthetic", "set_waymo", "lidar", "cfg3", "bev", "rl_loop")
+
+
+def stamp():
+    os.environ.setdefault("GPUDRIVE_MAX_AGENTS", "64")
+    import bench
+    return bench.source_stamp()
+
+
+traffic = {"source_stamp": stamp()}
 for tag in TAGS:
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     if not os.path.isdir(src):
@@ -23,16 +34,18 @@ for tag in TAGS:
         line = fh.read().strip().splitlines()[-1]
     with open(dst + "bench_under_rocprof.json", "w") as fh:
         fh.write(line + "\n")
+    for name in ("pmc_traffic_summary.json", "pmc_sq_summary.json", "occupancy.json"):
+        shutil.copy(os.path.join(src, name), dst + name.replace("_summary", ""))
     with open(os.path.join(src, "pmc_traffic_summary.json")) as fh:
         pmc = json.load(fh)
-    with open(dst + "pmc_traffic.json", "w") as fh:
-        json.dump(pmc, fh, indent=1)
     entry = {}
     for kern, c in pmc.items():
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
         f, w = c["FETCH_SIZE"]["mean"], c["WRITE_SIZE"]["mean"]
         entry[kern] = {"fetch_kib": f, "write_kib": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
-    road = entry.get("k_map_obs", {})
-    traffic[tag] = dict(road, kernels=entry)
+    road = sum(v["hbm_bytes_per_launch"] for k, v in entry.items() if k.startswith(("k_map_obs", "k_map_rows")))
+    traffic[tag] = dict(hbm_bytes_per_launch=road, kernels=entry)
 with open(os.path.join(ROOT, "profiles", ROUND + "_traffic.json"), "w") as fh:
     json.dump(traffic, fh, indent=1)
-print(json.dumps({t: round(v.get("hbm_bytes_per_launch", 0) / 1e6, 1) for t, v in traffic.items()}))
+print(json.dumps({t: round(v.get("hbm_bytes_per_launch", 0) / 1e6, 1) for t, v in traffic.items() if isinstance(v, dict)}))

@@ -1,36 +1,62 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for profiles/: kernel-trace stats of the bench command, then HBM
-# traffic counters (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, MI355X_MICROARCH.md "HBM").
-# Run on the GPU box:  gpurun -- tools/profile.sh <tag> [bench args...]
+# Collect the rocprofv3 evidence for profiles/ for ONE bench command (run on the GPU box):
+#   gpurun -- tools/profile.sh <tag> [bench args...]
+#   1. --kernel-trace --stats of the bench command        -> kernel_stats_summary.csv, occupancy.json (VGPR / LDS / waves)
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes (MI355X_MICROARCH.md "HBM")  -> pmc_traffic_summary.json
+#   3. --pmc SQ counter groups, separate passes            -> pmc_sq_summary.json
+# (no trace domains in the --pmc passes)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 91 --warmup 20 --no-cpu-baseline "$@" > $OUT/bench_trace.json 2>$OUT/trace.err
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 bench.py --steps 4 --warmup 1 --roofline-steps 1 --no-cpu-baseline "$@" > $OUT/bench_pmc_$C.json 2>$OUT/pmc_$C.err
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" \
+  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
+  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM"; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$i -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_pmc_$i.json 2>$OUT/pmc_$i.err
+  i=$((i+1))
 done
 python3 - <<PY
-import csv,glob,collections,json
+import csv,glob,collections,json,re
 out="$OUT"
-stats=glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True)
+KERNELS=("k_map_obs_set","k_map_obs","k_map_rows","k_world_step","k_lidar","k_bev","k_pack_obs","k_episode_step","k_reset_worlds")
+def kname(k):
+    m=re.search(r"(k_[a-z_]+(<[^>]*>)?)",k)
+    return m.group(1) if m else None
 rows=[]
-for f in stats:
+for f in glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True):
     rows+=list(csv.DictReader(open(f)))
 with open(out+"/kernel_stats_summary.csv","w") as fh:
     if rows:
         w=csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-for r in rows[:12]:
-    print({k:(v[:70] if isinstance(v,str) else v) for k,v in r.items()})
+for r in rows[:8]:
+    print({k:(v[:64] if isinstance(v,str) else v) for k,v in r.items() if k in ("Name","Calls","AverageNs","MinNs","MaxNs","Percentage")})
+# occupancy facts per kernel from the kernel trace
+occ={}
+for f in glob.glob(out+"/trace/**/*kernel_trace.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        n=kname(row.get("Kernel_Name",""))
+        if not n or n in occ: continue
+        g=lambda k: int(float(row.get(k,0) or 0))
+        vg=g("VGPR_Count")+g("Accum_VGPR_Count"); lds=g("LDS_Block_Size"); wg=g("Workgroup_Size")
+        waves_wg=max(1,(wg+63)//64)
+        alloc=-(-max(vg,1)//8)*8
+        by_vgpr=min(8,512//alloc)
+        by_lds=(160*1024//lds)*waves_wg/4.0 if lds else 8
+        occ[n]=dict(vgpr=g("VGPR_Count"),agpr=g("Accum_VGPR_Count"),sgpr=g("SGPR_Count"),lds_bytes_per_workgroup=lds,workgroup_size=wg,
+                    grid_size=g("Grid_Size"),waves_per_simd_by_vgpr=by_vgpr,waves_per_simd_by_lds=min(8,by_lds),
+                    waves_per_simd=min(8,by_vgpr,by_lds))
+json.dump(occ, open(out+"/occupancy.json","w"), indent=1)
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
-for C in ("FETCH_SIZE","WRITE_SIZE"):
-    for f in glob.glob(out+"/pmc_%s/**/*counter_collection.csv"%C, recursive=True):
-        for row in csv.DictReader(open(f)):
-            k=row["Kernel_Name"]
-            key=next((n for n in ("k_map_obs","k_world_step","k_lidar","k_bev") if n in k), None)
-            if key: agg[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
-summary={k:{c:{"mean":sum(x)/len(x),"n":len(x)} for c,x in v.items()} for k,v in agg.items()}
-json.dump(summary, open(out+"/pmc_traffic_summary.json","w"), indent=1)
-print(json.dumps(summary))
+for f in glob.glob(out+"/pmc_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        n=kname(row["Kernel_Name"])
+        if n: agg[n][row["Counter_Name"]].append(float(row["Counter_Value"]))
+traffic={k:{c:{"mean":sum(x)/len(x),"n":len(x)} for c,x in v.items() if c in ("FETCH_SIZE","WRITE_SIZE")} for k,v in agg.items()}
+sq={k:{c:sum(x)/len(x) for c,x in sorted(v.items()) if c.startswith("SQ_")} for k,v in agg.items()}
+json.dump(traffic, open(out+"/pmc_traffic_summary.json","w"), indent=1)
+json.dump(sq, open(out+"/pmc_sq_summary.json","w"), indent=1)
+print(json.dumps({k:{c:round(x["mean"]) for c,x in v.items()} for k,v in traffic.items()}))
 PY

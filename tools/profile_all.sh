@@ -1,8 +1,16 @@
 #!/bin/bash
-# Collect every profiles/ tag in one call on the GPU box:  gpurun --timeout 1200 -- tools/profile_all.sh
-set -e
-bash tools/profile.sh exact_synthetic --workloads synthetic > gpurun_out/prof_exact_synthetic.log 2>&1; echo "exact_synthetic done"
-bash tools/profile.sh exact_waymo --workloads waymo > gpurun_out/prof_exact_waymo.log 2>&1; echo "exact_waymo done"
-bash tools/profile.sh set_synthetic --workloads synthetic --knn-order 1 > gpurun_out/prof_set_synthetic.log 2>&1; echo "set_synthetic done"
-bash tools/profile.sh set_waymo --workloads waymo --knn-order 1 > gpurun_out/prof_set_waymo.log 2>&1; echo "set_waymo done"
-bash tools/profile.sh lidar --workloads lidar > gpurun_out/prof_lidar.log 2>&1; echo "lidar done"
+# Collect every profiles/ tag on the GPU box (about 10 minutes):  gpurun --timeout 1200 -- tools/profile_all.sh [tags...]
+TAGS=${@:-exact_synthetic exact_waymo set_synthetic set_waymo lidar cfg3 bev rl_loop}
+for t in $TAGS; do
+  case $t in
+    exact_synthetic) a="--workloads synthetic";;
+    exact_waymo) a="--workloads waymo";;
+    set_synthetic) a="--workloads synthetic --knn-order 1";;
+    set_waymo) a="--workloads waymo --knn-order 1";;
+    lidar) a="--workloads lidar";;
+    cfg3) a="--workloads cfg3";;
+    bev) a="--workloads bev";;
+    rl_loop) a="--workloads rl_loop";;
+  esac
+  timeout -k 10 400 bash tools/profile.sh $t $a > gpurun_out/prof_$t.log 2>&1 && echo "$t done" || echo "$t FAILED"
+done
