@@ -421,17 +421,19 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
 // selection lets the gather / atan2 / store work run at full occupancy instead of behind the LDS-bound selection waves.
 template <int A_T>
 __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
-    constexpr int U = 2;  // rows per thread (256 apart): two independent load chains in flight
+    constexpr int U = 2;          // rows per thread (256 apart): two independent load chains in flight
+    constexpr int RB = 256 * U;   // rows per workgroup: consecutive, so their 36-byte rows are one contiguous 18 KB block
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
+    __shared__ __attribute__((aligned(16))) float s_rows[RB * 9];
     const size_t rows = (size_t)d.W * A_T * K;
-    const size_t p0 = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * RB;
     // everything a row needs besides the road itself is requested at once (one round trip, not a chain of them)
     bool on[U], in[U];
     int r[U];
     float ex[U], ey[U], ew[U], ez[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const size_t p = p0 + (size_t)u * 256;
+        const size_t p = base + threadIdx.x + (size_t)u * 256;
         on[u] = p < rows;
         const size_t pc = on[u] ? p : 0;
         const size_t wa = pc / K;
@@ -453,28 +455,43 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
         q0[u] = d.road_aux[(size_t)r[u] * 2];
         q1[u] = d.road_aux[(size_t)r[u] * 2 + 1];
     }
-    // The rows are written once and not read again by the step: streaming (nt) stores keep them from pushing the
-    // road and agent arrays, which every step re-reads, out of L2 / Infinity Cache.
+    // The block's rows are assembled in LDS (row stride 9 floats: conflict-free) and leave as whole 16-byte pieces in
+    // row-major order, one piece per thread and pass; rows that must not be written (padding agents, beyond the
+    // tensor) are marked and their pieces skipped.  Streaming (nt) stores: the rows are written once and not read
+    // again by the step, and must not push the road and agent arrays out of L2 / Infinity Cache.
+    __shared__ unsigned char s_on[RB];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        if (!on[u]) continue;
-        float *o = d.agent_map + (p0 + (size_t)u * 256) * 9;
-        auto put = [&](float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8) {
-            __builtin_nontemporal_store(v0, o + 0); __builtin_nontemporal_store(v1, o + 1); __builtin_nontemporal_store(v2, o + 2);
-            __builtin_nontemporal_store(v3, o + 3); __builtin_nontemporal_store(v4, o + 4); __builtin_nontemporal_store(v5, o + 5);
-            __builtin_nontemporal_store(v6, o + 6); __builtin_nontemporal_store(v7, o + 7); __builtin_nontemporal_store(v8, o + 8);
-        };
+        const int lr = threadIdx.x + u * 256;
+        s_on[lr] = on[u] ? 1 : 0;
+        float *o = s_rows + lr * 9;
         if (!in[u]) {
             // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
             // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
             const float pad = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST ? 0.f : -1.f;
-            put(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (float)ET_None, pad, pad);
+            o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = (float)ET_None; o[7] = pad; o[8] = pad;
             continue;
         }
         const Quat einv = quat_inv(quat_from_wz(ew[u], ez[u]));
         const V2 rel = ego_relative(ex[u], ey[u], einv, xy[u].x, xy[u].y);
-        put(rel.x, rel.y, q0[u].z, q0[u].w, q1[u].x, quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0[u].x, q0[u].y))), q1[u].y, q1[u].z,
-            q1[u].w);
+        o[0] = rel.x; o[1] = rel.y; o[2] = q0[u].z; o[3] = q0[u].w; o[4] = q1[u].x;
+        o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0[u].x, q0[u].y)));
+        o[6] = q1[u].y; o[7] = q1[u].z; o[8] = q1[u].w;
+    }
+    __syncthreads();
+    float *out = d.agent_map + base * 9;  // base * 36 bytes: 16-byte aligned (RB * 36 is a multiple of 16)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int q = threadIdx.x; q < RB * 9 / 4; q += 256) {
+        const int r_lo = (q * 4) / 9, r_hi = (q * 4 + 3) / 9;  // the piece touches at most two rows
+        const bool a_on = s_on[r_lo] != 0, b_on = s_on[r_hi] != 0;
+        const f4 v = *reinterpret_cast<const f4 *>(s_rows + q * 4);
+        if (a_on && b_on) {
+            __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (size_t)q * 4));
+        } else if (a_on || b_on) {  // a piece shared with a row that must stay untouched: element by element
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (s_on[(q * 4 + e) / 9]) __builtin_nontemporal_store(v[e], out + (size_t)q * 4 + e);
+        }
     }
 }
 
@@ -653,7 +670,10 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
         }
         wave_sync();
         STAMP(t_f0);
-        count = heap.radius_filter(min(R, K), d.radius_key_max, s_ring + col, owner);
+        // radiusFilter (src/knn.hpp:156).  When the K-th distance itself is within the radius, every element of the heap
+        // is, and the filter moves nothing: the common case wherever roads are dense.
+        if (R >= K && __all(!live || heap.key(1) <= d.radius_key_max)) count = K;
+        else count = heap.radius_filter(min(R, K), d.radius_key_max, s_ring + col, owner);
 #ifdef GD_STAMPS
         st_filter = __builtin_amdgcn_s_memtime() - t_f0;
 #endif

@@ -40,13 +40,14 @@ for f in glob.glob(out+"/trace/**/*kernel_trace.csv", recursive=True):
         n=kname(row.get("Kernel_Name",""))
         if not n or n in occ: continue
         g=lambda k: int(float(row.get(k,0) or 0))
-        vg=g("VGPR_Count")+g("Accum_VGPR_Count"); lds=g("LDS_Block_Size"); wg=g("Workgroup_Size")
+        vg=g("VGPR_Count")+g("Accum_VGPR_Count"); lds=g("LDS_Block_Size")
+        wg=max(1,g("Workgroup_Size_X"))*max(1,g("Workgroup_Size_Y"))*max(1,g("Workgroup_Size_Z"))
         waves_wg=max(1,(wg+63)//64)
         alloc=-(-max(vg,1)//8)*8
         by_vgpr=min(8,512//alloc)
         by_lds=(160*1024//lds)*waves_wg/4.0 if lds else 8
         occ[n]=dict(vgpr=g("VGPR_Count"),agpr=g("Accum_VGPR_Count"),sgpr=g("SGPR_Count"),lds_bytes_per_workgroup=lds,workgroup_size=wg,
-                    grid_size=g("Grid_Size"),waves_per_simd_by_vgpr=by_vgpr,waves_per_simd_by_lds=min(8,by_lds),
+                    grid_size=max(1,g("Grid_Size_X"))*max(1,g("Grid_Size_Y"))*max(1,g("Grid_Size_Z")),waves_per_simd_by_vgpr=by_vgpr,waves_per_simd_by_lds=min(8,by_lds),
                     waves_per_simd=min(8,by_vgpr,by_lds))
 json.dump(occ, open(out+"/occupancy.json","w"), indent=1)
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
