@@ -1098,11 +1098,18 @@ static void collect_bev_obs(orc_sim *s, int w, int a) {
 /* ------------------------------------------------------------------ */
 /* lidarSystem, src/sim.cpp:394-460.                                   */
 /*                                                                     */
-/* PARITY UNPINNED: the reference traces rays through Madrona's 3-D BVH */
-/* (absent) against the collision meshes under assets/.  Restated    */
-/* from the mesh extents: cube_collision.obj is [-1,1]^3 and           */
-/* agent_collision_simplified.obj is [-1,1]^2 x [0,2], both scaled by  */
-/* the entity's Scale.  Rays are horizontal, so a ray at height z sees */
+/* MODELLED, PARITY UNPINNED: the reference traces rays through        */
+/* Madrona's 3-D BVH (absent) against the collision meshes under       */
+/* assets/ (src/mgr.cpp:273-279).  This is NOT a restatement of        */
+/* reference code but a model built from the only inputs the reference */
+/* holds: the vertex ranges of those meshes -- cube_collision.obj: 8   */
+/* vertices, x, y, z all in [-1, 1]; agent_collision_simplified.obj: 8 */
+/* vertices, x, y in [-1, 1], z in [0, 2] -- both scaled by the        */
+/* entity's Scale.  Nothing in the reference constrains the traversal  */
+/* (hit side, tie order, origin-inside rule); the rules below are this */
+/* build's choice, shared by the oracle and the kernel and by nothing  */
+/* else, so "oracle == kernel" is a self-consistency check, not parity.*/
+/* Rays are horizontal, so a ray at height z sees                      */
 /* exactly the entities whose scaled z-range contains z, as 2-D boxes: */
 /*   agents   z in [pos.z, pos.z + 2*0.7]                              */
 /*   road edge 1.1 +- 0.1; line/lane/crosswalk/speed bump 0.9 +- 0.1;  */
