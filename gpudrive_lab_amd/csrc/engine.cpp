@@ -100,6 +100,11 @@ struct gd_sim {
     std::vector<std::vector<gd::RoadBox>> w_boxes;
     std::vector<gd::GridHdr> w_grid;
     std::vector<std::vector<int32_t>> w_cell_off, w_cell_items;
+    std::vector<gd::GridHdr> w_rgrid;                    // grid over all roads (set-order selection)
+    std::vector<std::vector<int32_t>> w_rcell_off;
+    std::vector<std::vector<uint16_t>> w_rcell_items;
+    size_t rcell_cap = 0, ritem_cap = 0;
+    void *d_rcell_off = nullptr, *d_rcell_items = nullptr, *d_rcell_xy = nullptr;
     size_t cell_cap = 0, item_cap = 0;
     void *d_cell_off = nullptr, *d_cell_items = nullptr;
     size_t road_cap = 0, box_cap = 0;
@@ -127,6 +132,9 @@ struct gd_sim {
         if (d_boxes) (void)hipFree(d_boxes);
         if (d_cell_off) (void)hipFree(d_cell_off);
         if (d_cell_items) (void)hipFree(d_cell_items);
+        if (d_rcell_off) (void)hipFree(d_rcell_off);
+        if (d_rcell_items) (void)hipFree(d_rcell_items);
+        if (d_rcell_xy) (void)hipFree(d_rcell_xy);
         for (int i = 0; i < kRing; i++) {
             if (h_flags[i]) (void)hipHostFree(h_flags[i]);
             if (flag_ev[i]) (void)hipEventDestroy(flag_ev[i]);
@@ -379,6 +387,7 @@ struct gd_sim {
             w_grid[w] = gd::GridHdr{hw->grid_ox, hw->grid_oy, 1.f / hw->grid_cell, hw->grid_nx, hw->grid_ny, 0, 0, 0};
             w_cell_off[w] = hw->cell_off;
             w_cell_items[w] = hw->cell_items;
+            build_road_grid(w);
             rebuilt[w] = 1;
         }
         flush(run_start, run_len);
@@ -445,6 +454,7 @@ struct gd_sim {
             d.cell_items = static_cast<const int32_t *>(d_cell_items);
         }
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.road_off), road_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
+        upload_road_grids();
         {
             // longest-first launch order of the road kernel: its time per world grows with the road count
             std::vector<int32_t> order(W);
@@ -460,6 +470,87 @@ struct gd_sim {
         d.boxes = static_cast<const float4 *>(d_boxes);
         HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
         launch(gd::KERNEL_PADDING, false);
+    }
+
+    // Uniform grid over the (x, y) of ALL roads of world w: cells of at least 16 m, at most 64 x 64 of them; a road
+    // belongs to the cell its point falls into, and a cell lists its roads in ascending index.
+    void build_road_grid(int w) {
+        const std::vector<float> &xy = w_xy[w];
+        const size_t n = xy.size() / 2;
+        gd::GridHdr g{0.f, 0.f, 1.f, 1, 1, 0, 0, 0};
+        std::vector<int32_t> off(2, 0);
+        std::vector<uint16_t> items(n);
+        if (n) {
+            float minx = xy[0], maxx = xy[0], miny = xy[1], maxy = xy[1];
+            for (size_t r = 1; r < n; r++) {
+                minx = std::min(minx, xy[2 * r]); maxx = std::max(maxx, xy[2 * r]);
+                miny = std::min(miny, xy[2 * r + 1]); maxy = std::max(maxy, xy[2 * r + 1]);
+            }
+            const float cell = std::max(16.f, std::max(maxx - minx, maxy - miny) / 64.f + 1e-3f);
+            g.ox = minx; g.oy = miny; g.inv_cell = 1.f / cell;
+            g.nx = std::max(1, std::min(64, static_cast<int>((maxx - minx) * g.inv_cell) + 1));
+            g.ny = std::max(1, std::min(64, static_cast<int>((maxy - miny) * g.inv_cell) + 1));
+            const int nc = g.nx * g.ny;
+            std::vector<int32_t> cell_of(n);
+            off.assign(nc + 1, 0);
+            for (size_t r = 0; r < n; r++) {
+                const int cx = std::max(0, std::min(g.nx - 1, static_cast<int>((xy[2 * r] - g.ox) * g.inv_cell)));
+                const int cy = std::max(0, std::min(g.ny - 1, static_cast<int>((xy[2 * r + 1] - g.oy) * g.inv_cell)));
+                cell_of[r] = cy * g.nx + cx;
+                off[cell_of[r] + 1]++;
+            }
+            for (int c = 0; c < nc; c++) off[c + 1] += off[c];
+            std::vector<int32_t> fill(off.begin(), off.end() - 1);
+            for (size_t r = 0; r < n; r++) items[fill[cell_of[r]]++] = static_cast<uint16_t>(r);  // ascending r within a cell
+        }
+        w_rgrid[w] = g;
+        w_rcell_off[w] = std::move(off);
+        w_rcell_items[w] = std::move(items);
+    }
+
+    void upload_road_grids() {
+        size_t ncell = 0, nitem = 0;
+        for (int w = 0; w < W; w++) {
+            w_rgrid[w].cell_base = static_cast<int>(ncell);
+            w_rgrid[w].item_base = static_cast<int>(nitem);
+            ncell += w_rcell_off[w].size();
+            nitem += w_rcell_items[w].size();
+        }
+        if (ncell > rcell_cap) {
+            if (d_rcell_off) (void)hipFree(d_rcell_off);
+            rcell_cap = ncell + ncell / 8 + 64;
+            HIP_CHECK(hipMalloc(&d_rcell_off, rcell_cap * sizeof(int32_t)));
+        }
+        if (nitem + 64 > ritem_cap) {
+            if (d_rcell_items) (void)hipFree(d_rcell_items);
+            if (d_rcell_xy) (void)hipFree(d_rcell_xy);
+            ritem_cap = nitem + nitem / 8 + 128;
+            HIP_CHECK(hipMalloc(&d_rcell_items, ritem_cap * sizeof(uint16_t)));
+            HIP_CHECK(hipMalloc(&d_rcell_xy, ritem_cap * sizeof(float) * 2));
+        }
+        std::vector<int32_t> co(ncell);
+        std::vector<uint16_t> ci(nitem);
+        std::vector<float> cxy(nitem * 2);
+        for (int w = 0; w < W; w++) {
+            std::copy(w_rcell_off[w].begin(), w_rcell_off[w].end(), co.begin() + w_rgrid[w].cell_base);
+            std::copy(w_rcell_items[w].begin(), w_rcell_items[w].end(), ci.begin() + w_rgrid[w].item_base);
+            for (size_t k = 0; k < w_rcell_items[w].size(); k++) {
+                const size_t r = w_rcell_items[w][k], o = (static_cast<size_t>(w_rgrid[w].item_base) + k) * 2;
+                cxy[o] = w_xy[w][2 * r];
+                cxy[o + 1] = w_xy[w][2 * r + 1];
+            }
+        }
+        if (ncell) HIP_CHECK(hipMemcpy(d_rcell_off, co.data(), ncell * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (nitem) HIP_CHECK(hipMemcpy(d_rcell_items, ci.data(), nitem * sizeof(uint16_t), hipMemcpyHostToDevice));
+        if (nitem) HIP_CHECK(hipMemcpy(d_rcell_xy, cxy.data(), nitem * 2 * sizeof(float), hipMemcpyHostToDevice));
+        d.rcell_xy = static_cast<const float2 *>(d_rcell_xy);
+        HIP_CHECK(hipMemcpy(const_cast<gd::GridHdr *>(d.rgrid), w_rgrid.data(), sizeof(gd::GridHdr) * W, hipMemcpyHostToDevice));
+        d.rcell_off = static_cast<const int32_t *>(d_rcell_off);
+        d.rcell_items = static_cast<const uint16_t *>(d_rcell_items);
+        // the roads changed: no previous selection bounds the next one
+        std::vector<float> prev(static_cast<size_t>(W) * A * 4, 0.f);
+        for (size_t i = 0; i < static_cast<size_t>(W) * A; i++) prev[i * 4 + 2] = INFINITY;
+        HIP_CHECK(hipMemcpy(d.knn_prev, prev.data(), prev.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 
     void do_reset(const std::vector<int32_t> &flags) {
@@ -564,6 +655,9 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         s->w_grid.resize(W);
         s->w_cell_off.resize(W);
         s->w_cell_items.resize(W);
+        s->w_rgrid.resize(W);
+        s->w_rcell_off.resize(W);
+        s->w_rcell_items.resize(W);
         for (int id = 0; id < GD_T_COUNT; id++) {
             if (id == GD_T_BEV && !cfg->alloc_bev && !cfg->external[id]) continue;
             const int64_t bytes = spec_bytes(tensor_spec(id, W, A));
@@ -630,6 +724,8 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.world_order = s->alloc_internal<int32_t>(W);
         d.box_off = s->alloc_internal<int32_t>(W + 1);
         d.grid = s->alloc_internal<gd::GridHdr>(W);
+        d.rgrid = s->alloc_internal<gd::GridHdr>(W);
+        d.knn_prev = s->alloc_internal<float4>(WA);
         for (int i = 0; i < gd_sim::kRing; i++) {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->h_flags[i]), sizeof(int32_t) * W, hipHostMallocDefault));
             HIP_CHECK(hipEventCreateWithFlags(&s->flag_ev[i], hipEventDisableTiming));

@@ -59,6 +59,13 @@ struct DevSim {
     const GridHdr *grid;        // [W]
     const int32_t *cell_off;    // per world nx*ny+1 entries, local offsets
     const int32_t *cell_items;  // local box indices
+    // set-order road selection: per-world uniform grid over ALL roads (a road sits in the cell of its (x, y)), CSR of
+    // local road indices ascending within a cell, and per agent where and how far the previous selection reached
+    const GridHdr *rgrid;          // [W]
+    const int32_t *rcell_off;      // per world nx*ny+1 entries, local offsets
+    const uint16_t *rcell_items;   // local road indices
+    const float2 *rcell_xy;        // the (x, y) of those roads, in the same (cell-sorted) order: one coalesced stream per grid row
+    float4 *knn_prev;              // [W][A] {x, y, K-th key of the previous selection or +inf, 0}
 };
 
 void launch_kernel(const DevSim &d, hipStream_t st, int which, bool move);

@@ -55,6 +55,9 @@ constexpr int K = GD_MAP_OBS_K;
 #ifndef GD_TRIG_NUM
 #define GD_TRIG_NUM 4  // eighths of the live lanes that must be idle before the next chunk is scanned
 #endif
+#ifndef GD_ROWS_PER_THREAD
+#define GD_ROWS_PER_THREAD 2
+#endif
 #ifndef GD_MAP_OBS_AW
 #define GD_MAP_OBS_AW 32
 #endif
@@ -259,10 +262,12 @@ struct Heap {
         c[7] = true;
         float nk[8];
         unsigned int ni[8];
-        const float inf = __builtin_inff();
 #pragma unroll
         for (int l = 0; l < 8; l++) {
-            nk[l] = __builtin_amdgcn_fmed3f(l > 0 ? ck[l - 1] : inf, l < 7 ? ck[l] : -1.f, t.lk);
+            // the ends of the path have only one neighbour: a select on the predicate already computed
+            if (l == 0) nk[l] = c[0] ? t.lk : ck[0];
+            else if (l == 7) nk[l] = c[6] ? ck[6] : t.lk;
+            else nk[l] = __builtin_amdgcn_fmed3f(ck[l - 1], ck[l], t.lk);
             ni[l] = c[l] ? t.li : (l < 7 ? ci[l] : 0u);
             if (l > 0) ni[l] = c[l - 1] ? ci[l - 1] : ni[l];
         }
@@ -301,7 +306,9 @@ struct Heap {
         unsigned int oi[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            ok[u] = __builtin_amdgcn_fmed3f(u > 0 ? q[u - 1] : inf, u < 7 ? q[u] : -1.f, yk);
+            if (u == 0) ok[u] = p[0] ? yk : q[0];
+            else if (u == 7) ok[u] = p[6] ? q[6] : yk;
+            else ok[u] = __builtin_amdgcn_fmed3f(q[u - 1], q[u], yk);
             oi[u] = p[u] ? yi : (u < 7 ? qx[u] : 0u);
             if (u > 0) oi[u] = p[u - 1] ? qx[u - 1] : oi[u];
         }
@@ -421,7 +428,7 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
 // selection lets the gather / atan2 / store work run at full occupancy instead of behind the LDS-bound selection waves.
 template <int A_T>
 __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
-    constexpr int U = 2;          // rows per thread (256 apart): two independent load chains in flight
+    constexpr int U = GD_ROWS_PER_THREAD;  // rows per thread (256 apart): independent load chains in flight
     constexpr int RB = 256 * U;   // rows per workgroup: consecutive, so their 36-byte rows are one contiguous 18 KB block
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     __shared__ __attribute__((aligned(16))) float s_rows[RB * 9];
@@ -727,54 +734,42 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 
 // ---- set-order mode (gd_config.knn_order = GD_KNN_SET_ORDER) ----
 //
-// Same row SET as the reference (the K nearest by (distance^2, road index), then the radius filter),
-// rows in ascending road index instead of the reference's heap-history order.  Because the radius
-// filter runs after the top-K, the result is simply "every in-radius road" whenever at most K roads
-// are in radius, and the K smallest of the in-radius roads otherwise; no heap is needed.  Each wave
-// takes its agents one at a time with all 64 lanes on the road stream: 64 roads per iteration, ballot
-// compaction of the in-radius ones (key, road) into LDS in road order, and -- only when more than K are
-// in radius -- an exact selection by bisection on the key bits (ties at the K-th distance go to the
-// lowest road index).
-template <int A_T, int NW>
-__global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
-    const int w = blockIdx.x, tid = threadIdx.x;
-    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
-    const int wave = tid >> 6, lane = tid & 63;
-    const int n = d.shape[w * 2 + 0];
-    const int r0 = d.road_off[w];
-    const int R = d.road_off[w + 1] - r0;
-    const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
+// Same row SET as the reference (the K nearest by (distance^2, road index), then the radius filter), rows in
+// ascending road index instead of the reference's heap-history order.  Because the radius filter runs after the
+// top-K, the result is "every in-radius road" whenever fewer than K roads are in radius, and the K smallest of the
+// in-radius roads otherwise; no heap is needed.  Each wave takes its agents one at a time, all 64 lanes cooperating:
+//
+//   * BOUND.  The K roads selected last step lie within sqrt(T) of where the agent then was (T = that step's K-th
+//     key), hence within sqrt(T) + |movement| of where it is now: the new K-th distance cannot exceed that.  Only
+//     roads within min(radius, that bound) are candidates -- a few hundred instead of every in-radius road (1,700 of
+//     4,096 on the bench scene).  The bound is exact arithmetic on a conservative side (margin), holds for any
+//     reference point as long as the world's roads are the same (set_maps resets it), and a teleported agent simply
+//     gets the radius back.
+//   * GATHER through the world's road grid (engine.cpp build_road_grid): the cells a row of the bound's box crosses
+//     are one contiguous run of the CSR, so the lanes stride over whole rows; exact keys (ego_dist2), ballot
+//     compaction of (key, road) into LDS.
+//   * SELECT, only when more than K candidates: search on the key bits for the K-th smallest key with three probes
+//     per pass (counts packed in one register, one cross-lane reduction); ties at the K-th key go to the lowest road
+//     indices (the reference breaks such ties by heap position, the one documented difference of the set).
+//   * ORDER: the selected roads are marked in a bitmap over the world's road indices and read back in ascending
+//     order (popcount prefix over the lanes), straight into the selection scratch of k_map_rows.
+// The linear scan (AllEntitiesWithRadiusFiltering: first K in index order within the radius) and the rare agent with
+// more candidates than the LDS buffer holds take the full-stream path (select_streaming).
+template <int A_T>
+struct SetSel {
+    static constexpr int CAP = 1024;   // (key, road) candidates a wave holds in LDS
+    static constexpr int BMW = 320;    // bitmap words: 10,240 road indices
 
-    constexpr int CAP = 1024;  // in-radius candidates a wave can hold in LDS
-    __shared__ unsigned short s_idx[K * A_T];
-    __shared__ int s_count[A_T];
-    __shared__ float s_ckey[NW][CAP];
-    __shared__ unsigned short s_cidx[NW][CAP];
-
-    // selection: each wave takes its agents one at a time, all 64 lanes cooperating
-    constexpr int APW = A_T / NW;
-    float *ckey = s_ckey[wave];
-    unsigned short *cidx = s_cidx[wave];
-    const unsigned long long lower = (1ull << lane) - 1ull;
-    for (int al = 0; al < APW; al++) {
-        const int a = wave * APW + al;
-        if (a >= n) break;  // wave-uniform
-        const size_t i = (size_t)w * A_T + a;
-        const float ex = d.px[i], ey = d.py[i];
-        const Quat inv = quat_inv(quat_from_wz(d.qw[i], d.qz[i]));
-        // gather the in-radius candidates (key, road) in road order: lane = road, 64 consecutive roads per
-        // iteration in one coalesced load issued an iteration ahead (the world's (x, y) stream is re-read
-        // per agent from L1/L2; it reaches HBM once), ballot compaction into the wave's LDS buffer
+    // Full-stream selection (round 1's kernel): every road of the world, 256 per iteration; candidates recomputed from
+    // the stream when they do not fit the buffer.  Writes the selected road indices, ascending, to out[0..count).
+    static __device__ __forceinline__ int select_streaming(const DevSim &d, const float2 *rxy, int R, bool knn, float ex, float ey, float iw,
+                                                           float iz, float *ckey, unsigned short *cidx, unsigned short *out, int lane,
+                                                           float &kth) {
+        const unsigned long long lower = (1ull << lane) - 1ull;
         const float kmax = d.radius_key_max;
-        auto in_radius = [&](float key) -> bool {
-            // radiusFilter keeps length() <= radius (src/knn.hpp:88); the linear scan skips length() > radius.
-            // sqrtf is monotone and correctly rounded, so both are comparisons of the squared key with
-            // radius_key_max, the largest fp32 whose square root is <= radius (computed at gd_create)
-            return knn ? (key <= kmax) : !(key > kmax);
-        };
-        const float2 *rxy = d.road_xy + r0;
+        auto in_radius = [&](float key) -> bool { return knn ? (key <= kmax) : !(key > kmax); };
         int nin = 0;
-        constexpr int U = 4;  // 64-road groups per iteration: U loads in flight per lane, issued an iteration ahead
+        constexpr int U = 4;
         float2 nxt[U];
 #pragma unroll
         for (int u = 0; u < U; u++) nxt[u] = u * 64 + lane < R ? rxy[u * 64 + lane] : make_float2(0.f, 0.f);
@@ -789,7 +784,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int r = rb + u * 64 + lane;
-                const float key = ego_dist2(ex, ey, inv.w, inv.z, cur[u].x, cur[u].y);
+                const float key = ego_dist2(ex, ey, iw, iz, cur[u].x, cur[u].y);
                 const bool in = r < R && in_radius(key);
                 const unsigned long long b = __ballot(in);
                 const int pos = nin + __popcll(b & lower);
@@ -799,85 +794,247 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         }
         wave_sync();
         int count = 0;
+        kth = __builtin_inff();
         if (nin <= K || !knn) {
-            // every in-radius road (k-NN), or the first K of them (linear scan), in road order
             count = min(nin, K);
-            for (int j = lane; j < count; j += 64) s_idx[j * A_T + a] = cidx[j];
-        } else if (nin < CAP) {
-            // K smallest by (key, road): bisection on the key bits for the K-th smallest key T
-            // (largest T with count(key < T) < K), then everything below T plus the earliest ties
-            // three probes per pass (counts packed 11 + 11 + 10 bits, nin < 1024: one cross-lane reduction
-            // for all three): the search interval shrinks four-fold per pass, 16 passes for the 31 key bits
-            unsigned int lo = 0u, hi = 0x7f800000u;
-            while (lo < hi) {
-                const unsigned int step = (hi - lo + 3u) / 4u;  // >= 1
-                const unsigned int p1 = lo + step, p2 = min(hi, p1 + step), p3 = min(hi, p2 + step);
-                unsigned int cnt = 0;
-                for (int j = lane; j < nin; j += 64) {
-                    const unsigned int kb = __float_as_uint(ckey[j]);
-                    cnt += (kb < p1 ? 1u : 0u) + (kb < p2 ? 1u << 11 : 0u) + (kb < p3 ? 1u << 22 : 0u);
-                }
-                for (int off = 32; off > 0; off >>= 1) cnt += (unsigned int)__shfl_xor((int)cnt, off);
-                const int c1 = (int)(cnt & 2047u), c2 = (int)((cnt >> 11) & 2047u), c3 = (int)(cnt >> 22);
-                if (c3 < K) lo = p3;
-                else if (c2 < K) { lo = p2; hi = p3 - 1u; }
-                else if (c1 < K) { lo = p1; hi = p2 - 1u; }
-                else hi = p1 - 1u;
-            }
-            int less = 0;
-            for (int j = lane; j < nin; j += 64) less += __float_as_uint(ckey[j]) < lo ? 1 : 0;
-            for (int off = 32; off > 0; off >>= 1) less += __shfl_xor(less, off);
-            int need_ties = K - less;
-            for (int jb = 0; jb < nin; jb += 64) {
-                const int j = jb + lane;
-                const unsigned int kb = j < nin ? __float_as_uint(ckey[j]) : 0xffffffffu;
-                const bool tie = kb == lo;
-                const unsigned long long tb = __ballot(tie);
-                const bool take = kb < lo || (tie && (int)__popcll(tb & lower) < need_ties);
-                need_ties -= min(need_ties, __popcll(tb));
-                const unsigned long long kb2 = __ballot(take);
-                if (take) s_idx[(count + __popcll(kb2 & lower)) * A_T + a] = cidx[j];
-                count += __popcll(kb2);
-            }
+            for (int j = lane; j < count; j += 64) out[j] = cidx[j];
         } else {
-            // more in-radius roads than the LDS candidate buffer holds: same selection, keys recomputed
-            // from the road stream on every bisection step
-            auto key_bits = [&](int r, bool &in) -> unsigned int {
-                in = false;
+            auto key_bits = [&](int j, int r) -> unsigned int {  // candidate j of the buffer, or road r of the stream
+                if (nin < CAP) return j < nin ? __float_as_uint(ckey[j]) : 0xffffffffu;
                 if (r >= R) return 0xffffffffu;
                 const float2 xy = rxy[r];
-                const float key = ego_dist2(ex, ey, inv.w, inv.z, xy.x, xy.y);
-                in = in_radius(key);
-                return in ? __float_as_uint(key) : 0xffffffffu;
+                const float key = ego_dist2(ex, ey, iw, iz, xy.x, xy.y);
+                return in_radius(key) ? __float_as_uint(key) : 0xffffffffu;
             };
+            const int n = nin < CAP ? nin : R;
             unsigned int lo = 0u, hi = 0x7f800000u;
             while (lo < hi) {
                 const unsigned int mid = lo + (hi - lo + 1) / 2;
                 int cnt = 0;
-                for (int rb = 0; rb < R; rb += 64) { bool in; cnt += __popcll(__ballot(key_bits(rb + lane, in) < mid)); }
+                for (int jb = 0; jb < n; jb += 64) cnt += __popcll(__ballot(key_bits(jb + lane, jb + lane) < mid));
                 if (cnt < K) lo = mid; else hi = mid - 1;
             }
             int less = 0;
-            for (int rb = 0; rb < R; rb += 64) { bool in; less += __popcll(__ballot(key_bits(rb + lane, in) < lo)); }
+            for (int jb = 0; jb < n; jb += 64) less += __popcll(__ballot(key_bits(jb + lane, jb + lane) < lo));
             int need_ties = K - less;
-            for (int rb = 0; rb < R; rb += 64) {
-                bool in;
-                const unsigned int kb = key_bits(rb + lane, in);
-                const bool tie = in && kb == lo;
+            for (int jb = 0; jb < n; jb += 64) {  // buffer and stream are both in road order: earliest ties win
+                const int j = jb + lane;
+                const unsigned int kb = key_bits(j, j);
+                const bool tie = kb == lo;
                 const unsigned long long tb = __ballot(tie);
-                const bool take = (in && kb < lo) || (tie && (int)__popcll(tb & lower) < need_ties);
-                need_ties -= min(need_ties, __popcll(tb));
+                const bool take = kb < lo || (tie && (int)__popcll(tb & lower) < need_ties);
+                need_ties -= min(need_ties, (int)__popcll(tb));
                 const unsigned long long kb2 = __ballot(take);
-                if (take) s_idx[(count + __popcll(kb2 & lower)) * A_T + a] = (unsigned short)(rb + lane);
+                if (take) out[count + __popcll(kb2 & lower)] = nin < CAP ? cidx[j] : (unsigned short)j;
                 count += __popcll(kb2);
             }
+            kth = __uint_as_float(lo);
         }
-        if (lane == 0) s_count[a] = min(count, K);
+        return count;
+    }
+};
+
+template <int A_T, int NW>
+__global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
+    using S = SetSel<A_T>;
+    constexpr int CAP = S::CAP, BMW = S::BMW;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
+    const int wave = tid >> 6, lane = tid & 63;
+    const int n = d.shape[w * 2 + 0];
+    const int r0 = d.road_off[w];
+    const int R = d.road_off[w + 1] - r0;
+    const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
+
+    __shared__ float s_ckey[NW][CAP];
+    __shared__ unsigned short s_cidx[NW][CAP];
+    __shared__ unsigned int s_bits[NW][BMW];
+    float *ckey = s_ckey[wave];
+    unsigned short *cidx = s_cidx[wave];
+    unsigned int *bits = s_bits[wave];
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const float2 *rxy = d.road_xy + r0;
+    const GridHdr g = d.rgrid[w];
+    const int32_t *coff = d.rcell_off + g.cell_base;
+    const uint16_t *citems = d.rcell_items + g.item_base;
+    const float2 *cxy = d.rcell_xy + g.item_base;
+    const float kmax = d.radius_key_max;
+
+    for (int a = wave; a < n; a += NW) {  // wave-uniform
+        const size_t i = (size_t)w * A_T + a;
+        const float ex = d.px[i], ey = d.py[i];
+        const float iw = d.qw[i], iz = -d.qz[i];  // the INVERSE rotation
+        unsigned short *out = d.sel_idx + i * K;
+        int count = 0;
+        float kth = __builtin_inff();
+        bool done = false;
+        if (knn && R > 0) {
+            // candidates: within the radius AND within what the previous selection allows
+            // (the K-th distance is 1-Lipschitz in the agent's position: it also cannot fall below sqrt(T) - |movement|,
+            // which gives the search for the new T a narrow starting interval)
+            const float4 pv = d.knn_prev[i];
+            float bound = kmax, floor_key = 0.f;
+            if (pv.z < __builtin_inff()) {
+                const float dx = ex - pv.x, dy = ey - pv.y;
+                const float move = sqrtf(dx * dx + dy * dy);
+                const float reach = sqrtf(pv.z) * 1.0001f + move * 1.0001f + 1e-3f;
+                bound = fminf(bound, reach * reach * 1.0001f);
+                const float near = sqrtf(pv.z) * 0.9999f - move * 1.0001f - 1e-3f;
+                floor_key = near > 0.f ? near * near * 0.9999f : 0.f;
+            }
+            // rows of the grid the bound's box crosses (a slightly larger box: cells are chosen in plain float)
+            const float rr = sqrtf(bound) * 1.001f + 1e-2f;
+            const int cx0 = max(0, min(g.nx - 1, (int)floorf((ex - rr - g.ox) * g.inv_cell)));
+            const int cx1 = max(0, min(g.nx - 1, (int)floorf((ex + rr - g.ox) * g.inv_cell)));
+            const int cy0 = max(0, min(g.ny - 1, (int)floorf((ey - rr - g.oy) * g.inv_cell)));
+            const int cy1 = max(0, min(g.ny - 1, (int)floorf((ey + rr - g.oy) * g.inv_cell)));
+            // roads left of column 0 / right of the last column were clamped into the border cells at build time; an
+            // agent outside the grid reaches them through the clamped cell range
+            // the run of every grid row, fetched in one go (lane q holds row cy0 + q; the grid has at most 64 rows)
+            const int nrows = cy1 - cy0 + 1;
+            int run_lo = 0, run_hi = 0;
+            if (lane < nrows) {
+                run_lo = coff[(cy0 + lane) * g.nx + cx0];
+                run_hi = coff[(cy0 + lane) * g.nx + cx1 + 1];
+            }
+            // One coalesced 64-road piece per iteration, (index, x, y) from the cell-sorted copies; the next piece is
+            // requested before the current one is keyed.
+            int nin = 0, q = 0;
+            int j0 = __builtin_amdgcn_readlane(run_lo, 0), j1 = __builtin_amdgcn_readlane(run_hi, 0), jb = j0;
+            auto settle = [&]() {  // move (q, jb) to the next non-empty piece; q == nrows when there is none
+                while (q < nrows && jb >= j1) {
+                    q++;
+                    if (q < nrows) {
+                        j0 = __builtin_amdgcn_readlane(run_lo, q);
+                        j1 = __builtin_amdgcn_readlane(run_hi, q);
+                        jb = j0;
+                    }
+                }
+            };
+            auto fetch = [&](int &r, float2 &xy, bool &ok) {
+                const int j = jb + lane;
+                ok = q < nrows && j < j1;
+                r = ok ? (int)citems[j] : 0;
+                xy = ok ? cxy[j] : make_float2(0.f, 0.f);
+            };
+            settle();
+            int r_cur, r_nxt;
+            float2 xy_cur, xy_nxt;
+            bool ok_cur, ok_nxt;
+            fetch(r_cur, xy_cur, ok_cur);
+            while (q < nrows) {
+                jb += 64;
+                settle();
+                fetch(r_nxt, xy_nxt, ok_nxt);
+                const float key = ego_dist2(ex, ey, iw, iz, xy_cur.x, xy_cur.y);
+                const bool in = ok_cur && key <= bound;
+                const unsigned long long b = __ballot(in);
+                const int pos = nin + __popcll(b & lower);
+                if (in && pos < CAP) { ckey[pos] = key; cidx[pos] = (unsigned short)r_cur; }
+                nin += __popcll(b);
+                r_cur = r_nxt; xy_cur = xy_nxt; ok_cur = ok_nxt;
+            }
+            wave_sync();
+            if (nin <= CAP) {
+                done = true;
+                for (int q = lane; q < BMW; q += 64) bits[q] = 0u;
+                wave_sync();
+                if (nin < K) {  // fewer than K roads within the bound: then the bound is the radius, and all of them are selected
+                    for (int j = lane; j < nin; j += 64) atomicOr(&bits[cidx[j] >> 5], 1u << (cidx[j] & 31));
+                    count = nin;
+                } else {
+                    // the K-th smallest key T: largest T with count(key < T) < K.  The candidates' key bits sit in
+                    // registers (lane l holds candidates l, l + 64, ...); three probes per pass, counted with ballots
+                    // (scalar popcounts: no cross-lane traffic), so the interval shrinks four-fold per pass.
+                    constexpr int KR = CAP / 64;
+                    unsigned int kb[KR];
+#pragma unroll
+                    for (int u = 0; u < KR; u++) kb[u] = u * 64 + lane < nin ? __float_as_uint(ckey[u * 64 + lane]) : 0xffffffffu;
+                    const int nu = (nin + 63) >> 6;
+                    auto count_below = [&](unsigned int p) -> int {
+                        int c = 0;
+#pragma unroll
+                        for (int u = 0; u < KR; u++)
+                            if (u < nu) c += __popcll(__ballot(kb[u] < p));
+                        return c;
+                    };
+                    // T lies in [floor_key, bound]: count(key < floor_key) < K (fewer than K roads can be that close), and
+                    // every candidate is <= bound
+                    unsigned int lo = __float_as_uint(floor_key), hi = __float_as_uint(bound);
+                    while (lo < hi) {
+                        const unsigned int step = (hi - lo + 3u) / 4u;  // >= 1
+                        const unsigned int p1 = lo + step, p2 = min(hi, p1 + step), p3 = min(hi, p2 + step);
+                        int c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+                        for (int u = 0; u < KR; u++) {
+                            if (u < nu) {
+                                c1 += __popcll(__ballot(kb[u] < p1));
+                                c2 += __popcll(__ballot(kb[u] < p2));
+                                c3 += __popcll(__ballot(kb[u] < p3));
+                            }
+                        }
+                        if (c3 < K) lo = p3;
+                        else if (c2 < K) { lo = p2; hi = p3 - 1u; }
+                        else if (c1 < K) { lo = p1; hi = p2 - 1u; }
+                        else hi = p1 - 1u;
+                    }
+                    // everything below T, then the lowest road indices among the ties at T
+                    const int less = count_below(lo);
+#pragma unroll
+                    for (int u = 0; u < KR; u++) {
+                        if (u < nu && kb[u] < lo) {
+                            const unsigned int r = cidx[u * 64 + lane];
+                            atomicOr(&bits[r >> 5], 1u << (r & 31));
+                        }
+                    }
+                    unsigned int floor_idx = 0;  // ties with a road index below this are already taken
+                    for (int t = less; t < K; t++) {  // almost always one iteration
+                        unsigned int best = 0xffffffffu;
+                        for (int j = lane; j < nin; j += 64)
+                            if (__float_as_uint(ckey[j]) == lo && (unsigned int)cidx[j] >= floor_idx) best = min(best, (unsigned int)cidx[j]);
+                        for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned int)__shfl_xor((int)best, off));
+                        if (best == 0xffffffffu) break;  // cannot happen: at least K candidates have a key <= T
+                        if (lane == 0) bits[best >> 5] |= 1u << (best & 31);
+                        floor_idx = best + 1u;
+                        wave_sync();
+                    }
+                    count = K;
+                    kth = __uint_as_float(lo);
+                }
+                wave_sync();
+                // read the bitmap back in ascending road order.  Lane l owns words l, l + 64, ... (neighbouring roads are
+                // selected together, so consecutive words go to different lanes); an inclusive prefix sum over the lanes
+                // per group of 64 words (DPP row shifts and row broadcasts: no LDS round trips) gives every word its place.
+                constexpr int WPL = BMW / 64;
+                int base = 0;
+#pragma unroll
+                for (int q = 0; q < WPL; q++) {
+                    unsigned int m = bits[q * 64 + lane];
+                    const int pre = __popc(m);
+                    int incl = pre;
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+                    int pos = base + incl - pre;
+                    base += __builtin_amdgcn_readlane(incl, 63);
+                    while (m) {
+                        const int bit = __ffs(m) - 1;
+                        m &= m - 1u;
+                        out[pos++] = (unsigned short)((q * 64 + lane) * 32 + bit);
+                    }
+                }
+            }
+        }
+        if (!done) count = S::select_streaming(d, rxy, R, knn, ex, ey, iw, iz, ckey, cidx, out, lane, kth);
+        if (lane == 0) {
+            d.sel_count[i] = min(count, K);
+            d.knn_prev[i] = make_float4(ex, ey, kth, 0.f);
+        }
         wave_sync();
     }
-    __syncthreads();
-    store_selection<A_T>(d, w, 0, n, [&](int c, int sl) -> int { return s_idx[sl * A_T + c]; }, [&](int c) -> int { return s_count[c]; },
-                         tid, NW * 64);
 }
 
 }  // namespace
@@ -886,14 +1043,14 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
     if (d.knn_order == GD_KNN_SET_ORDER) {
         const dim3 grid(d.W);
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4>), grid, dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((k_map_obs_set<128, 8>), grid, dim3(512), 0, st, d);
+        else hipLaunchKernelGGL((k_map_obs_set<128, 4>), grid, dim3(256), 0, st, d);
     } else {
         const dim3 grid(d.W * (d.A / AW));
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64>), grid, dim3(64), 0, st, d);
         else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);
     }
     const size_t rows = (size_t)d.W * d.A * K;
-    const dim3 rgrid((unsigned int)((rows + 511) / 512));  // two rows per thread
+    const dim3 rgrid((unsigned int)((rows + 256 * GD_ROWS_PER_THREAD - 1) / (256 * GD_ROWS_PER_THREAD)));
     if (d.A == 64) hipLaunchKernelGGL((k_map_rows<64>), rgrid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((k_map_rows<128>), rgrid, dim3(256), 0, st, d);
 }
