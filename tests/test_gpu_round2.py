@@ -298,3 +298,43 @@ def test_gym_wrapper_call_sequence_on_the_device(oracle_mod):
         assert torch.allclose(obs, packed, atol=3e-7, rtol=1e-6)
         gpu.debug_set_state(orc.get_state())   # keep the two simulators on the same state (teacher forcing)
     gpu.close()
+
+
+def test_set_order_bounds_survive_resets_and_map_changes(oracle_mod):
+    """The set-order selection prunes with last step's K-th distance (a bound that moves with the agent).  Free-running
+    steps carry it over; a reset teleports agents (the bound must open up to the radius again) and set_maps changes the
+    roads under them (the bound must be dropped): the rows must stay the reference's as a set through all of it."""
+    scenes = [TEST_JSON, SCENE_407, SCENE_4]
+    kw = dict(CLASSIC, polylineReductionThreshold=0.0, observationRadius=60.0)   # thousands of roads: K binds
+    gpu = P.make_gpu_sim(scenes, max_agents=64, knn_order=1, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    rng = np.random.default_rng(17)
+
+    def advance(k):
+        for _ in range(k):
+            act = P.random_actions(rng, orc.W, orc.A, 0)
+            RC.write_actions(gpu, act)
+            np.copyto(orc.action_tensor(), act)
+            gpu.step()
+            orc.step()
+            gpu.debug_set_state(orc.get_state())   # same state on both sides, then one more coherent recompute
+            gpu.reset([])
+            orc.reset([])
+            P.compare_roadmap_as_set(gpu, orc)
+    advance(6)
+    gpu.reset([0, 2])                                # agents jump back to their logged start poses
+    orc.reset([0, 2])
+    gpu.debug_set_state(orc.get_state())
+    gpu.reset([])
+    orc.reset([])
+    P.compare_roadmap_as_set(gpu, orc)
+    advance(3)
+    new = [SCENE_4, TEST_JSON, SCENE_407]            # other roads under the same agent slots
+    gpu.set_maps(new)
+    orc.set_maps(new)
+    gpu.debug_set_state(orc.get_state())
+    gpu.reset([])
+    orc.reset([])
+    P.compare_roadmap_as_set(gpu, orc)
+    advance(3)
+    gpu.close()
