@@ -674,6 +674,15 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.A = A;
         d.p = *params;
         d.knn_order = cfg->knn_order;
+        {
+            // Set-order mode has two equivalent write-outs (map_obs.hip, launch_map_obs): rows stored by the selecting wave
+            // pay off once the worlds outnumber the resident workgroups (4 per CU) at least twice.  The choice never changes
+            // a result; GPUDRIVE_SET_FUSED_ROWS=0|1 pins it (the tests run both on small batches).
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
+            d.set_fused_rows = W >= 8 * cus ? 1 : 0;
+            if (const char *e = std::getenv("GPUDRIVE_SET_FUSED_ROWS")) d.set_fused_rows = std::atoi(e) != 0 ? 1 : 0;
+        }
         d.lidar_half_angle = cfg->lidar_half_angle;
         {
             // radiusFilter keeps length() <= radius (src/knn.hpp:88); on squared keys: key <= kmax

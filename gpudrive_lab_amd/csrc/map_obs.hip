@@ -84,11 +84,16 @@ struct Heap {
     float *k;
     unsigned short *i;
     __device__ __forceinline__ float key(int g) const { return k[g * AW]; }
+#ifdef GD_EXPT_KEYONLY  // timing experiment: no index array (results are wrong)
+    __device__ __forceinline__ unsigned int index(int g) const { return 0u; }
+    __device__ __forceinline__ void set(int g, float key, unsigned int idx) const { k[g * AW] = key; }
+#else
     __device__ __forceinline__ unsigned int index(int g) const { return i[g * AW]; }
     __device__ __forceinline__ void set(int g, float key, unsigned int idx) const {
         k[g * AW] = key;
         i[g * AW] = (unsigned short)idx;
     }
+#endif
     __device__ __forceinline__ void move(int dst, int src) const { set(dst, key(src), index(src)); }
     // make_heap, src/binary_heap.hpp:170-185.  The reference sifts parents K/2, ..., 1 in turn; parents on one tree
     // level own disjoint subtrees, so they commute: the heap is built level by level from the bottom, N parents
@@ -385,7 +390,10 @@ struct Heap {
 };
 
 // Per-agent cursor over the ring of candidate words, and one round of the drain.
-constexpr int RING = 16;  // chunks of candidate words an agent may lag behind the scan
+#ifndef GD_RING
+#define GD_RING 16
+#endif
+constexpr int RING = GD_RING;  // chunks of candidate words an agent may lag behind the scan
 constexpr int C = 32;     // roads per chunk = one candidate word
 struct Drain {
     unsigned int word = 0;  // unread candidate bits of chunk `cw`
@@ -426,6 +434,24 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
 // One thread per (world, agent, slot) row of agent_roadmap_tensor; a wave writes 64 consecutive 36-byte rows.  The row is
 // ReferenceFrame::observationOf (src/utils.hpp:36-49) of the selected road, or the padding row.  Splitting it from the
 // selection lets the gather / atan2 / store work run at full occupancy instead of behind the LDS-bound selection waves.
+// One row of agent_roadmap_tensor into o[0..9): the selected road seen from the agent at (ex, ey) with rotation (ew, ez), or
+// the padding row.
+__device__ __forceinline__ void road_row(float *o, bool selected, bool knn, float ex, float ey, float ew, float ez, float2 xy, float4 q0,
+                                         float4 q1) {
+    if (!selected) {
+        // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
+        // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
+        const float pad = knn ? 0.f : -1.f;
+        o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = (float)ET_None; o[7] = pad; o[8] = pad;
+        return;
+    }
+    const Quat einv = quat_inv(quat_from_wz(ew, ez));
+    const V2 rel = ego_relative(ex, ey, einv, xy.x, xy.y);
+    o[0] = rel.x; o[1] = rel.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x;
+    o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0.x, q0.y)));
+    o[6] = q1.y; o[7] = q1.z; o[8] = q1.w;
+}
+
 template <int A_T>
 __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     constexpr int U = GD_ROWS_PER_THREAD;  // rows per thread (256 apart): independent load chains in flight
@@ -471,19 +497,8 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     for (int u = 0; u < U; u++) {
         const int lr = threadIdx.x + u * 256;
         s_on[lr] = on[u] ? 1 : 0;
-        float *o = s_rows + lr * 9;
-        if (!in[u]) {
-            // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
-            // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
-            const float pad = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST ? 0.f : -1.f;
-            o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = (float)ET_None; o[7] = pad; o[8] = pad;
-            continue;
-        }
-        const Quat einv = quat_inv(quat_from_wz(ew[u], ez[u]));
-        const V2 rel = ego_relative(ex[u], ey[u], einv, xy[u].x, xy[u].y);
-        o[0] = rel.x; o[1] = rel.y; o[2] = q0[u].z; o[3] = q0[u].w; o[4] = q1[u].x;
-        o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0[u].x, q0[u].y)));
-        o[6] = q1[u].y; o[7] = q1[u].z; o[8] = q1[u].w;
+        road_row(s_rows + lr * 9, in[u], d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST, ex[u], ey[u], ew[u], ez[u], xy[u], q0[u],
+                 q1[u]);
     }
     __syncthreads();
     float *out = d.agent_map + base * 9;  // base * 36 bytes: 16-byte aligned (RB * 36 is a multiple of 16)
@@ -538,10 +553,18 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 
     // one buffer, carved by hand: the ring comes first so that the 1-based heap columns (row g - 1 of the arrays,
     // i.e. base - one row + g rows) never form an address below the buffer
+#ifdef GD_EXPT_KEYONLY
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[RING * AW * 4 + SLOTS * AW * 4];
+#else
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[RING * AW * 4 + SLOTS * AW * 6];
+#endif
     unsigned int *s_ring = reinterpret_cast<unsigned int *>(s_buf);  // word of ring slot c of column l at [c * AW + l]
     float *s_keys = reinterpret_cast<float *>(s_buf + RING * AW * 4) - AW;                                    // [g * AW + col], g >= 1
+#ifdef GD_EXPT_KEYONLY
+    unsigned short *s_idx = reinterpret_cast<unsigned short *>(s_buf + RING * AW * 4) - AW;
+#else
     unsigned short *s_idx = reinterpret_cast<unsigned short *>(s_buf + RING * AW * 4 + SLOTS * AW * 4) - AW;  // [g * AW + idx_col]
+#endif
 
     const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
     const Heap heap{s_keys + col, s_idx + idx_col(col)};
@@ -720,7 +743,12 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     if (owner) s_count[col] = live ? min(count, K) : 0;
     wave_sync();
     STAMP(t_w0);
-    store_selection<A_T>(d, w, a0, min(AW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; },
+    store_selection<A_T>(d, w, a0, min(AW, n - a0), 
+#ifdef GD_EXPT_KEYONLY
+                         [&](int c, int sl) -> int { return sl; },
+#else
+                         [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; },
+#endif
                          [&](int c) -> int { return s_count[c]; }, lane, 64);
 #ifdef GD_STAMPS
     if (lane == 0 && blockIdx.x < 8192) {
@@ -834,7 +862,7 @@ struct SetSel {
     }
 };
 
-template <int A_T, int NW>
+template <int A_T, int NW, bool FUSE>
 __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
     using S = SetSel<A_T>;
     constexpr int CAP = S::CAP, BMW = S::BMW;
@@ -849,6 +877,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
     __shared__ float s_ckey[NW][CAP];
     __shared__ unsigned short s_cidx[NW][CAP];
     __shared__ unsigned int s_bits[NW][BMW];
+    __shared__ unsigned short s_sel[NW][K];
     float *ckey = s_ckey[wave];
     unsigned short *cidx = s_cidx[wave];
     unsigned int *bits = s_bits[wave];
@@ -864,7 +893,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         const size_t i = (size_t)w * A_T + a;
         const float ex = d.px[i], ey = d.py[i];
         const float iw = d.qw[i], iz = -d.qz[i];  // the INVERSE rotation
-        unsigned short *out = d.sel_idx + i * K;
+        unsigned short *out = FUSE ? s_sel[wave] : d.sel_idx + i * K;  // the selected road indices, ascending
         int count = 0;
         float kth = __builtin_inff();
         bool done = false;
@@ -1029,11 +1058,43 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
             }
         }
         if (!done) count = S::select_streaming(d, rxy, R, knn, ex, ey, iw, iz, ckey, cidx, out, lane, kth);
+        count = min(count, K);
         if (lane == 0) {
-            d.sel_count[i] = min(count, K);
             d.knn_prev[i] = make_float4(ex, ey, kth, 0.f);
+            if (!FUSE) d.sel_count[i] = count;
         }
         wave_sync();
+        if (!FUSE) continue;  // k_map_rows writes the rows
+        // ---- FUSE: the agent's K rows, written by the wave that selected them.  With several generations of workgroups
+        // (many worlds) the HBM-bound row stores of one workgroup overlap the issue-bound selection of the others; when every
+        // workgroup is resident at once the separate, fully occupied k_map_rows is the faster write-out (launch_map_obs) ----
+        constexpr int NP = (K + 63) / 64;
+        static_assert(K % 4 == 0 && S::CAP >= 64 * 9, "whole 16-byte pieces; the staging block fits the key buffer");
+        float2 xy[NP];
+        float4 q0[NP], q1[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {  // every gather of the agent requested at once
+            const int sl = p * 64 + lane;
+            const int r = r0 + (sl < count ? (int)out[sl] : 0);
+            xy[p] = d.road_xy[r];
+            q0[p] = d.road_aux[(size_t)r * 2];
+            q1[p] = d.road_aux[(size_t)r * 2 + 1];
+        }
+        // 64 rows at a time are laid out in LDS (the candidate keys' buffer is free now) and leave as whole 16-byte pieces
+        // of one contiguous block: an agent's rows start at a multiple of 7200 bytes and 64 rows are 2304, both multiples of 16
+        float *stage = ckey;
+        float *rows_out = d.agent_map + i * (size_t)(K * 9);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int sl = p * 64 + lane;
+            road_row(stage + lane * 9, sl < count, knn, ex, ey, iw, -iz, xy[p], q0[p], q1[p]);
+            wave_sync();
+            const int pieces = min(64, K - p * 64) * 9 / 4;
+            for (int q = lane; q < pieces; q += 64)
+                __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(rows_out + p * 576 + q * 4));
+            wave_sync();
+        }
     }
 }
 
@@ -1042,8 +1103,13 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
 void launch_map_obs(const DevSim &d, hipStream_t st) {
     if (d.knn_order == GD_KNN_SET_ORDER) {
         const dim3 grid(d.W);
-        if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4>), grid, dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((k_map_obs_set<128, 4>), grid, dim3(256), 0, st, d);
+        if (d.set_fused_rows) {
+            if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4, true>), grid, dim3(256), 0, st, d);
+            else hipLaunchKernelGGL((k_map_obs_set<128, 4, true>), grid, dim3(256), 0, st, d);
+            return;
+        }
+        if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4, false>), grid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((k_map_obs_set<128, 4, false>), grid, dim3(256), 0, st, d);
     } else {
         const dim3 grid(d.W * (d.A / AW));
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64>), grid, dim3(64), 0, st, d);

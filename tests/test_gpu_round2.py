@@ -43,7 +43,9 @@ def test_lockstep_parity_on_the_bench_scenes(oracle_mod, bench_scenes):
     gpu.close()
 
 
-def test_set_order_on_the_bench_scenes(oracle_mod, bench_scenes):
+@pytest.mark.parametrize("rows", ["rows_kernel", "rows_fused"])
+def test_set_order_on_the_bench_scenes(oracle_mod, bench_scenes, monkeypatch, rows):
+    monkeypatch.setenv("GPUDRIVE_SET_FUSED_ROWS", "1" if rows == "rows_fused" else "0")
     gpu = P.make_gpu_sim(bench_scenes, max_agents=64, knn_order=1, **BENCH)
     orc = P.make_oracle_sim(oracle_mod, bench_scenes, max_agents=64, **BENCH)
     rng = np.random.default_rng(5)
