@@ -6,18 +6,31 @@
 #include "engine.hpp"
 #include "gd_math.hpp"
 
+#ifdef GD_STAMPS
+// diagnostic build only (tools/stamps.sh bev): per-workgroup cycle counts of the phases of k_bev
+__device__ unsigned long long g_bev_stamps[8192][8];
+extern "C" int gd_debug_read_bev_stamps(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bev_stamps), sizeof(unsigned long long) * 8 * n);
+}
+#define BEV_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define BEV_STAMP(var)
+#endif
+
 namespace gd {
 
 namespace {
 
 constexpr int K = GD_MAP_OBS_K;
 constexpr int RES = GD_BEV_RES;
+#ifndef GD_BEV_BANDS
+#define GD_BEV_BANDS 4  // bands of 50 grid rows: 40,000 bytes of cells (measured: 4 bands 2.04 ms, 5 2.16, 8 2.42)
+#endif
 
 // ------------------------------------------------------------------------------------------
-// BEV.  Entities are painted in the reference's order (first <= 200 in-radius roads in road order,
-// then in-radius partners in OtherAgents order; later paints overwrite earlier ones).  The grid
-// lives in LDS as one byte per cell; each wave owns a band of grid rows and paints every entity
-// clipped to its rows, so paint order needs no barrier.
+// BEV.  The reference paints the first <= 200 in-radius roads in road order, then the in-radius partners in
+// OtherAgents order; later paints overwrite earlier ones.  Here a cell keeps the entity with the highest
+// position in that order (LDS atomic max), which is the same picture painted in any order.
 // ------------------------------------------------------------------------------------------
 struct BevEnt {
     float cx, cy, cosy, siny, half_l, half_w;
@@ -55,8 +68,8 @@ __device__ __forceinline__ BevEnt bev_entity(float cx, float cy, float yaw, floa
 
 template <int A_T, int NT>
 __global__ __launch_bounds__(NT) void k_bev(DevSim d) {
-    constexpr int NWV = NT / 64;  // waves; each owns RES / NWV grid rows
-    static_assert(RES % NWV == 0 && NT >= 128, "geometry");
+    constexpr int NWV = NT / 64;  // waves
+    static_assert(NT >= 128 && NT % 64 == 0, "geometry");
     const int a = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int n = d.shape[w * 2 + 0];
@@ -68,16 +81,17 @@ __global__ __launch_bounds__(NT) void k_bev(DevSim d) {
     const size_t i = (size_t)w * A_T + a;
 
     constexpr int MAXE = K + GD_MAX_AGENTS_LIMIT;
-    __shared__ unsigned char s_grid[RES * RES];
+    __shared__ __attribute__((aligned(16))) unsigned int s_cells[RES * RES / GD_BEV_BANDS];  // one band of rows, 32-bit cells
     __shared__ BevEnt s_ent[MAXE];
     __shared__ int s_wcnt[NWV];
     __shared__ int s_ne;
 
+    BEV_STAMP(t_begin);
     const float ex = d.px[i], ey = d.py[i];
     const Quat rot = quat_from_wz(d.qw[i], d.qz[i]);
     const Quat inv = quat_inv(rot);
 
-    for (int c = tid; c < RES * RES / 4; c += NT) reinterpret_cast<unsigned int *>(s_grid)[c] = 0u;
+    for (int c = tid; c < RES * RES / GD_BEV_BANDS; c += NT) s_cells[c] = 0u;
 
     // ---- roads: first K in-radius in road order (src/sim.cpp:484-523) ----
     int count = 0;
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(NT) void k_bev(DevSim d) {
         count = min(count + total, K);
         __syncthreads();
     }
+    BEV_STAMP(t_roads);
     // ---- partners in OtherAgents order (src/sim.cpp:526-554) ----
     {
         const int j = tid;  // A_T <= 128 <= NT
@@ -134,52 +149,61 @@ __global__ __launch_bounds__(NT) void k_bev(DevSim d) {
         __syncthreads();
     }
     const int ne = s_ne;
+    BEV_STAMP(t_ents);
 
-    // ---- paint: wave `wave` owns rows [(RES/NWV)*wave, (RES/NWV)*(wave+1)) ----
-    // 64 entities at a time, one per lane: a ballot names the ones whose cell range meets this wave's rows,
-    // and only those are painted, in entity order (ascending lane, ascending batch), their parameters
-    // broadcast to the wave as scalars.
-    const int row_lo = wave * (RES / NWV), row_hi = row_lo + RES / NWV - 1;
+    // ---- paint and write out, one band of BR grid rows at a time ----
+    // A cell holds (entity position + 1) << 8 | type and is updated with an LDS atomic max, so "the last entity in the
+    // reference's order wins" holds whatever the order in which lanes get there: the entities are painted concurrently,
+    // one per group of 16 lanes (road segments cover a few dozen cells; with one entity per wave and the rows dealt to
+    // waves in bands, the wave that owned the rows around the agent did nearly all the work).  Bands keep the 32-bit
+    // cells within the 40,000 bytes the byte grid used to take.
+    constexpr int NB = GD_BEV_BANDS, BR = RES / NB, NG = NT / 16;
+    static_assert(BR * NB == RES && (BR * RES) % 4 == 0, "bands");
+    const int grp = tid >> 4, sl = tid & 15;
     const float scale_px = (2 * radius) / RES;
-    auto bcast_f = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
-    for (int eb = 0; eb < ne; eb += 64) {
-        const int e = eb + lane;
-        BevEnt mine{};
-        if (e < ne) mine = s_ent[e];
-        const int my0 = max(mine.y0, row_lo), my1 = min(mine.y1, row_hi);
-        unsigned long long todo = __ballot(e < ne && my1 >= my0 && mine.x1 >= mine.x0);
-        while (todo) {
-            const int l = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const float cx = bcast_f(mine.cx, l), cy = bcast_f(mine.cy, l);
-            const float cosy = bcast_f(mine.cosy, l), siny = bcast_f(mine.siny, l);
-            const float half_l = bcast_f(mine.half_l, l), half_w = bcast_f(mine.half_w, l);
-            const int x0 = __builtin_amdgcn_readlane(mine.x0, l), x1 = __builtin_amdgcn_readlane(mine.x1, l);
-            const int y0 = __builtin_amdgcn_readlane(my0, l), y1 = __builtin_amdgcn_readlane(my1, l);
-            const unsigned char type = (unsigned char)__builtin_amdgcn_readlane(mine.type, l);
-            const int nx = x1 - x0 + 1, cells = nx * (y1 - y0 + 1);
+    float4 *out = reinterpret_cast<float4 *>(d.bev + i * (size_t)(RES * RES));
+    for (int band = 0; band < NB; band++) {
+        const int row_lo = band * BR, row_hi = row_lo + BR - 1;
+        for (int e = grp; e < ne; e += NG) {
+            const BevEnt en = s_ent[e];
+            const int y0 = max(en.y0, row_lo), y1 = min(en.y1, row_hi);
+            if (y1 < y0 || en.x1 < en.x0) continue;
+            const int nx = en.x1 - en.x0 + 1, cells = nx * (y1 - y0 + 1);
             const float inv_nx = 1.f / (float)nx;
-            for (int c = lane; c < cells; c += 64) {
+            const unsigned int val = ((unsigned int)(e + 1) << 8) | (unsigned int)(en.type & 0xff);
+            for (int c = sl; c < cells; c += 16) {
                 int q = (int)(((float)c + 0.5f) * inv_nx);  // c / nx for c < 40,000 (checked and corrected below)
                 q -= q * nx > c ? 1 : 0;
                 q += (q + 1) * nx <= c ? 1 : 0;
-                const int y = y0 + q, x = x0 + c - q * nx;
+                const int y = y0 + q, x = en.x0 + c - q * nx;
                 const float px = x * scale_px - radius, py = y * scale_px - radius;
-                const float ldx = px - cx, ldy = py - cy;
-                const float lx = ldx * cosy - ldy * siny;
-                const float ly = ldx * siny + ldy * cosy;
+                const float ldx = px - en.cx, ldy = py - en.cy;
+                const float lx = ldx * en.cosy - ldy * en.siny;
+                const float ly = ldx * en.siny + ldy * en.cosy;
                 const float epsilon = 1e-3f;
-                if (fabsf(lx) <= half_l + epsilon && fabsf(ly) <= half_w + epsilon) s_grid[y * RES + x] = type;
+                if (fabsf(lx) <= en.half_l + epsilon && fabsf(ly) <= en.half_w + epsilon) atomicMax(&s_cells[(y - row_lo) * RES + x], val);
             }
         }
+        __syncthreads();
+        // the band leaves as floats (float4 stores) and is zeroed for the next one on the way
+        for (int c = tid; c < BR * RES / 4; c += NT) {
+            const uint4 v = reinterpret_cast<const uint4 *>(s_cells)[c];
+            reinterpret_cast<uint4 *>(s_cells)[c] = make_uint4(0u, 0u, 0u, 0u);
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 cellv = {(float)(v.x & 0xff), (float)(v.y & 0xff), (float)(v.z & 0xff), (float)(v.w & 0xff)};
+            __builtin_nontemporal_store(cellv, reinterpret_cast<f4 *>(out + band * (BR * RES / 4) + c));  // written once, not read by the step
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // ---- write-out: 40,000 floats, float4 stores ----
-    float4 *out = reinterpret_cast<float4 *>(d.bev + i * (size_t)(RES * RES));
-    for (int c = tid; c < RES * RES / 4; c += NT) {
-        const unsigned int v = reinterpret_cast<const unsigned int *>(s_grid)[c];
-        out[c] = make_float4((float)(v & 0xff), (float)((v >> 8) & 0xff), (float)((v >> 16) & 0xff), (float)(v >> 24));
+#ifdef GD_STAMPS
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0 && wg < 8192) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = g_bev_stamps[wg];
+        o[0] = t_end - t_begin; o[1] = t_roads - t_begin; o[2] = t_ents - t_roads; o[3] = t_end - t_ents; o[4] = 0;
+        o[5] = 0; o[6] = (unsigned long long)ne; o[7] = (unsigned long long)R;
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -84,16 +84,11 @@ struct Heap {
     float *k;
     unsigned short *i;
     __device__ __forceinline__ float key(int g) const { return k[g * AW]; }
-#ifdef GD_EXPT_KEYONLY  // timing experiment: no index array (results are wrong)
-    __device__ __forceinline__ unsigned int index(int g) const { return 0u; }
-    __device__ __forceinline__ void set(int g, float key, unsigned int idx) const { k[g * AW] = key; }
-#else
     __device__ __forceinline__ unsigned int index(int g) const { return i[g * AW]; }
     __device__ __forceinline__ void set(int g, float key, unsigned int idx) const {
         k[g * AW] = key;
         i[g * AW] = (unsigned short)idx;
     }
-#endif
     __device__ __forceinline__ void move(int dst, int src) const { set(dst, key(src), index(src)); }
     // make_heap, src/binary_heap.hpp:170-185.  The reference sifts parents K/2, ..., 1 in turn; parents on one tree
     // level own disjoint subtrees, so they commute: the heap is built level by level from the bottom, N parents
@@ -553,18 +548,10 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 
     // one buffer, carved by hand: the ring comes first so that the 1-based heap columns (row g - 1 of the arrays,
     // i.e. base - one row + g rows) never form an address below the buffer
-#ifdef GD_EXPT_KEYONLY
-    __shared__ __attribute__((aligned(16))) unsigned char s_buf[RING * AW * 4 + SLOTS * AW * 4];
-#else
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[RING * AW * 4 + SLOTS * AW * 6];
-#endif
     unsigned int *s_ring = reinterpret_cast<unsigned int *>(s_buf);  // word of ring slot c of column l at [c * AW + l]
     float *s_keys = reinterpret_cast<float *>(s_buf + RING * AW * 4) - AW;                                    // [g * AW + col], g >= 1
-#ifdef GD_EXPT_KEYONLY
-    unsigned short *s_idx = reinterpret_cast<unsigned short *>(s_buf + RING * AW * 4) - AW;
-#else
     unsigned short *s_idx = reinterpret_cast<unsigned short *>(s_buf + RING * AW * 4 + SLOTS * AW * 4) - AW;  // [g * AW + idx_col]
-#endif
 
     const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
     const Heap heap{s_keys + col, s_idx + idx_col(col)};
@@ -743,12 +730,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     if (owner) s_count[col] = live ? min(count, K) : 0;
     wave_sync();
     STAMP(t_w0);
-    store_selection<A_T>(d, w, a0, min(AW, n - a0), 
-#ifdef GD_EXPT_KEYONLY
-                         [&](int c, int sl) -> int { return sl; },
-#else
-                         [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; },
-#endif
+    store_selection<A_T>(d, w, a0, min(AW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; },
                          [&](int c) -> int { return s_count[c]; }, lane, 64);
 #ifdef GD_STAMPS
     if (lane == 0 && blockIdx.x < 8192) {
