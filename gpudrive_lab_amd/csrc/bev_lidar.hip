@@ -34,8 +34,14 @@ constexpr int RES = GD_BEV_RES;
 // ------------------------------------------------------------------------------------------
 struct BevEnt {
     float cx, cy, cosy, siny, half_l, half_w;
-    int x0, x1, y0, y1, type;  // cell range to test (inclusive)
+    unsigned int box;  // cell range to test (inclusive): x0 | x1 << 8 | y0 << 16 | y1 << 24; an empty range is stored as x0 = 1, x1 = 0
+    int type;
+    __device__ __forceinline__ int x0() const { return (int)(box & 0xff); }
+    __device__ __forceinline__ int x1() const { return (int)((box >> 8) & 0xff); }
+    __device__ __forceinline__ int y0() const { return (int)((box >> 16) & 0xff); }
+    __device__ __forceinline__ int y1() const { return (int)(box >> 24); }
 };
+static_assert(sizeof(BevEnt) == 32 && RES <= 256, "32-byte entities, 8-bit cell coordinates");
 
 __device__ __forceinline__ BevEnt bev_entity(float cx, float cy, float yaw, float length, float width, int type,
                                              float radius) {
@@ -61,13 +67,17 @@ __device__ __forceinline__ BevEnt bev_entity(float cx, float cy, float yaw, floa
     const float hy = e.half_l * fabsf(e.siny) + e.half_w * fabsf(e.cosy) + 2e-3f;
     const int tx0 = (int)floorf((cx - hx + radius) * scale_m) - 1, tx1 = (int)ceilf((cx + hx + radius) * scale_m) + 1;
     const int ty0 = (int)floorf((cy - hy + radius) * scale_m) - 1, ty1 = (int)ceilf((cy + hy + radius) * scale_m) + 1;
-    e.x0 = max(max(gx - br, 0), tx0); e.x1 = min(min(gx + br, RES - 1), tx1);
-    e.y0 = max(max(gy - br, 0), ty0); e.y1 = min(min(gy + br, RES - 1), ty1);
+    const int x0 = max(max(gx - br, 0), tx0), x1 = min(min(gx + br, RES - 1), tx1);
+    const int y0 = max(max(gy - br, 0), ty0), y1 = min(min(gy + br, RES - 1), ty1);
+    e.box = (x1 < x0 || y1 < y0) ? 1u : (unsigned int)x0 | (unsigned int)x1 << 8 | (unsigned int)y0 << 16 | (unsigned int)y1 << 24;
     return e;
 }
 
+#ifndef GD_BEV_WAVES_PER_SIMD
+#define GD_BEV_WAVES_PER_SIMD 6  // three workgroups of 512 threads per CU (LDS: 48.5 KB each)
+#endif
 template <int A_T, int NT>
-__global__ __launch_bounds__(NT) void k_bev(DevSim d) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(GD_BEV_WAVES_PER_SIMD, 8))) void k_bev(DevSim d) {
     constexpr int NWV = NT / 64;  // waves
     static_assert(NT >= 128 && NT % 64 == 0, "geometry");
     const int a = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(NT) void k_bev(DevSim d) {
     const float radius = d.p.observationRadius;
     const size_t i = (size_t)w * A_T + a;
 
-    constexpr int MAXE = K + GD_MAX_AGENTS_LIMIT;
+    constexpr int MAXE = K + A_T;  // <= K roads and A_T - 1 partners
     __shared__ __attribute__((aligned(16))) unsigned int s_cells[RES * RES / GD_BEV_BANDS];  // one band of rows, 32-bit cells
     __shared__ BevEnt s_ent[MAXE];
     __shared__ int s_wcnt[NWV];
@@ -162,20 +172,23 @@ __global__ __launch_bounds__(NT) void k_bev(DevSim d) {
     const int grp = tid >> 4, sl = tid & 15;
     const float scale_px = (2 * radius) / RES;
     float4 *out = reinterpret_cast<float4 *>(d.bev + i * (size_t)(RES * RES));
+#pragma clang loop unroll(disable)
     for (int band = 0; band < NB; band++) {
         const int row_lo = band * BR, row_hi = row_lo + BR - 1;
+#pragma clang loop unroll(disable)
         for (int e = grp; e < ne; e += NG) {
             const BevEnt en = s_ent[e];
-            const int y0 = max(en.y0, row_lo), y1 = min(en.y1, row_hi);
-            if (y1 < y0 || en.x1 < en.x0) continue;
-            const int nx = en.x1 - en.x0 + 1, cells = nx * (y1 - y0 + 1);
+            const int ex0 = en.x0(), ex1 = en.x1();
+            const int y0 = max(en.y0(), row_lo), y1 = min(en.y1(), row_hi);
+            if (y1 < y0 || ex1 < ex0) continue;
+            const int nx = ex1 - ex0 + 1, cells = nx * (y1 - y0 + 1);
             const float inv_nx = 1.f / (float)nx;
             const unsigned int val = ((unsigned int)(e + 1) << 8) | (unsigned int)(en.type & 0xff);
             for (int c = sl; c < cells; c += 16) {
                 int q = (int)(((float)c + 0.5f) * inv_nx);  // c / nx for c < 40,000 (checked and corrected below)
                 q -= q * nx > c ? 1 : 0;
                 q += (q + 1) * nx <= c ? 1 : 0;
-                const int y = y0 + q, x = en.x0 + c - q * nx;
+                const int y = y0 + q, x = ex0 + c - q * nx;
                 const float px = x * scale_px - radius, py = y * scale_px - radius;
                 const float ldx = px - en.cx, ldy = py - en.cy;
                 const float lx = ldx * en.cosy - ldy * en.siny;
@@ -186,6 +199,7 @@ __global__ __launch_bounds__(NT) void k_bev(DevSim d) {
         }
         __syncthreads();
         // the band leaves as floats (float4 stores) and is zeroed for the next one on the way
+#pragma clang loop unroll_count(2)
         for (int c = tid; c < BR * RES / 4; c += NT) {
             const uint4 v = reinterpret_cast<const uint4 *>(s_cells)[c];
             reinterpret_cast<uint4 *>(s_cells)[c] = make_uint4(0u, 0u, 0u, 0u);

@@ -21,7 +21,7 @@ buf = (ctypes.c_ulonglong * (8 * n))()
 rc = lib.gd_debug_read_bev_stamps(buf, n)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.float64)
 a = a[a[:, 0] > 0]
-names = ["total", "clear + road scan", "partners", "paint (wave 0)", "wait for the other waves", "write-out", "entities", "roads"]
+names = ["total", "clear + road scan", "partners", "paint (wave 0, 4 bands)", "wait for the other waves", "write-out + barrier", "entities", "roads"]
 print("workload", wl, "workgroups", len(a), "rc", rc)
 for i, nm in enumerate(names):
     print("  %-26s mean %10.0f  min %10.0f  max %10.0f" % (nm, a[:, i].mean(), a[:, i].min(), a[:, i].max()))
