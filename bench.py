@@ -186,7 +186,10 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
     # the source stamp of the build it was collected on; another build gets null.
     traffic = None
     try:
-        tkey = ("set_" if args.knn_order == 1 else "exact_") + workload
+        if workload in ("synthetic", "waymo"):
+            tkey = ("set_" if args.knn_order == 1 else "exact_") + workload
+        else:  # lidar, bev, rl_loop: collected in the default (reference) row order only
+            tkey = workload if args.knn_order == 0 else ("set_cfg3" if workload == "cfg3" else None)
         with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
             tj = json.load(fh)
         if tj.get("source_stamp") == source_stamp() and args.worlds == 1024 and args.agents == 64:

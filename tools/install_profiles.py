@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
-TAGS = ("exact_synthetic", "exact_waymo", "set_synthetic", "set_waymo", "lidar", "cfg3", "bev", "rl_loop")
+TAGS = ("exact_synthetic", "exact_waymo", "set_synthetic", "set_waymo", "lidar", "cfg3", "set_cfg3", "bev", "rl_loop")
 
 
 def stamp():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect every profiles/ tag on the GPU box (about 10 minutes):  gpurun --timeout 1200 -- tools/profile_all.sh [tags...]
-TAGS=${@:-exact_synthetic exact_waymo set_synthetic set_waymo lidar cfg3 bev rl_loop}
+TAGS=${@:-exact_synthetic exact_waymo set_synthetic set_waymo lidar cfg3 set_cfg3 bev rl_loop}
 for t in $TAGS; do
   case $t in
     exact_synthetic) a="--workloads synthetic";;
@@ -9,6 +9,7 @@ for t in $TAGS; do
     set_waymo) a="--workloads waymo --knn-order 1";;
     lidar) a="--workloads lidar";;
     cfg3) a="--workloads cfg3";;
+    set_cfg3) a="--workloads cfg3 --knn-order 1";;
     bev) a="--workloads bev";;
     rl_loop) a="--workloads rl_loop";;
   esac
