@@ -108,7 +108,7 @@ struct gd_sim {
     size_t cell_cap = 0, item_cap = 0;
     void *d_cell_off = nullptr, *d_cell_items = nullptr;
     size_t road_cap = 0, box_cap = 0;
-    void *d_road_xy = nullptr, *d_road_aux = nullptr, *d_boxes = nullptr;
+    void *d_road_xy = nullptr, *d_road_aux = nullptr, *d_road_rec = nullptr, *d_boxes = nullptr;
     // pinned flag staging ring
     static constexpr int kRing = 8;
     int32_t *h_flags[kRing] = {};
@@ -129,6 +129,7 @@ struct gd_sim {
         for (void *p : internal) (void)hipFree(p);
         if (d_road_xy) (void)hipFree(d_road_xy);
         if (d_road_aux) (void)hipFree(d_road_aux);
+        if (d_road_rec) (void)hipFree(d_road_rec);
         if (d_boxes) (void)hipFree(d_boxes);
         if (d_cell_off) (void)hipFree(d_cell_off);
         if (d_cell_items) (void)hipFree(d_cell_items);
@@ -401,9 +402,11 @@ struct gd_sim {
         if (nroad > road_cap) {
             if (d_road_xy) (void)hipFree(d_road_xy);
             if (d_road_aux) (void)hipFree(d_road_aux);
+            if (d_road_rec) (void)hipFree(d_road_rec);
             road_cap = nroad + nroad / 8 + 320;  // k_map_obs requests chunks of 32 roads up to 256 roads past a world's last one
             HIP_CHECK(hipMalloc(&d_road_xy, road_cap * sizeof(float) * 2));
             HIP_CHECK(hipMalloc(&d_road_aux, road_cap * sizeof(float) * 8));
+            HIP_CHECK(hipMalloc(&d_road_rec, road_cap * sizeof(float) * 8));
         }
         if (nbox > box_cap) {
             if (d_boxes) (void)hipFree(d_boxes);
@@ -421,7 +424,23 @@ struct gd_sim {
             if (nroad) {
                 HIP_CHECK(hipMemcpy(d_road_xy, xy.data(), xy.size() * sizeof(float), hipMemcpyHostToDevice));
                 HIP_CHECK(hipMemcpy(d_road_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice));
+                // the row kernel's 32-byte record: aux is (qw, qz, d0, d1, d2, type, id, mapType); d2 is 1 for stop signs and
+                // 0.1 for everything else (scene.cpp put_road callers), which the kernel restores from the type
+                std::vector<float> rec(nroad * 8);
+                for (size_t r = 0; r < nroad; r++) {
+                    const float *a = &aux[r * 8];
+                    if (a[4] != (static_cast<int>(a[5]) == gd::ET_StopSign ? 1.f : 0.1f))
+                        throw std::runtime_error("road record: unexpected z scale for this entity type");
+                    const uint32_t bits = (static_cast<uint32_t>(static_cast<int>(a[5])) & 0xffu) |
+                                          (static_cast<uint32_t>(static_cast<int>(a[7]) + 1) << 8);
+                    float fb;
+                    std::memcpy(&fb, &bits, sizeof(fb));
+                    const float row[8] = {xy[r * 2], xy[r * 2 + 1], a[0], a[1], a[2], a[3], a[6], fb};
+                    std::copy(row, row + 8, rec.begin() + r * 8);
+                }
+                HIP_CHECK(hipMemcpy(d_road_rec, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
             }
+            HIP_CHECK(hipMemset(d.sel_hdr, 0xff, sizeof(float4) * 2 * static_cast<size_t>(W) * d.A));  // count -1: nothing selected yet
             if (nbox) HIP_CHECK(hipMemcpy(d_boxes, boxes.data(), nbox * sizeof(gd::RoadBox), hipMemcpyHostToDevice));
         }
         {
@@ -467,6 +486,7 @@ struct gd_sim {
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.box_off), box_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
         d.road_xy = static_cast<const float2 *>(d_road_xy);
         d.road_aux = static_cast<const float4 *>(d_road_aux);
+        d.road_rec = static_cast<const float4 *>(d_road_rec);
         d.boxes = static_cast<const float4 *>(d_boxes);
         HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
         launch(gd::KERNEL_PADDING, false);
@@ -724,7 +744,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.etype = s->alloc_internal<int32_t>(WA); d.agent_id = s->alloc_internal<int32_t>(WA);
         d.resp = s->alloc_internal<int32_t>(WA);
         d.sel_idx = s->alloc_internal<uint16_t>(static_cast<size_t>(WA) * GD_MAP_OBS_K);
-        d.sel_count = s->alloc_internal<int32_t>(WA);
+        d.sel_hdr = s->alloc_internal<float4>(static_cast<size_t>(WA) * 2);
         d.reset_flags = s->alloc_internal<int32_t>(W);
         d.rebuilt_flags = s->alloc_internal<int32_t>(W);
         d.any_reset = s->alloc_internal<int32_t>(1);

@@ -44,7 +44,8 @@ struct DevSim {
     int32_t *etype, *agent_id, *resp;
     // road selection scratch: what k_map_obs / k_map_obs_set hand to k_map_rows
     uint16_t *sel_idx;    // [W][A][K] road index (within the world) of every selected slot, in output order
-    int32_t *sel_count;   // [W][A] selected rows per agent (rows beyond it are padding)
+    float4 *sel_hdr;      // [W][A][2] per agent for k_map_rows: (x, y, qw, qz) and, as int bits, (selected rows, first road of the
+                          // world, 0, 0); the count is -1 where this launch selected nothing (padding agents)
     // per world flags
     int32_t *reset_flags, *rebuilt_flags;
     int32_t *any_reset;    // one int: k_episode_step raised at least one reset flag in this step
@@ -55,6 +56,7 @@ struct DevSim {
     const int32_t *world_order;  // [W] worlds by decreasing road count: the road kernel starts its longest workgroups first
     const float2 *road_xy;
     const float4 *road_aux;
+    const float4 *road_rec;  // [roads][2] what a row of agent_roadmap_tensor needs, in 32 bytes: (x, y, qw, qz), (d0, d1, id, bits: type | (mapType + 1) << 8)
     const int32_t *box_off;   // [W+1]
     const float4 *boxes;
     const GridHdr *grid;        // [W]

@@ -429,10 +429,9 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
 // One thread per (world, agent, slot) row of agent_roadmap_tensor; a wave writes 64 consecutive 36-byte rows.  The row is
 // ReferenceFrame::observationOf (src/utils.hpp:36-49) of the selected road, or the padding row.  Splitting it from the
 // selection lets the gather / atan2 / store work run at full occupancy instead of behind the LDS-bound selection waves.
-// One row of agent_roadmap_tensor into o[0..9): the selected road seen from the agent at (ex, ey) with rotation (ew, ez), or
-// the padding row.
-__device__ __forceinline__ void road_row(float *o, bool selected, bool knn, float ex, float ey, float ew, float ez, float2 xy, float4 q0,
-                                         float4 q1) {
+// One row of agent_roadmap_tensor into o[0..9): the selected road (its 32-byte record, engine.hpp road_rec) seen from the agent
+// at (ex, ey) with rotation (ew, ez), or the padding row.
+__device__ __forceinline__ void road_row(float *o, bool selected, bool knn, float ex, float ey, float ew, float ez, float4 q0, float4 q1) {
     if (!selected) {
         // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
         // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
@@ -440,11 +439,14 @@ __device__ __forceinline__ void road_row(float *o, bool selected, bool knn, floa
         o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = (float)ET_None; o[7] = pad; o[8] = pad;
         return;
     }
+    const unsigned int bits = __float_as_uint(q1.w);
+    const int type = (int)(bits & 0xffu), map_type = (int)(bits >> 8) - 1;
     const Quat einv = quat_inv(quat_from_wz(ew, ez));
-    const V2 rel = ego_relative(ex, ey, einv, xy.x, xy.y);
-    o[0] = rel.x; o[1] = rel.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x;
-    o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0.x, q0.y)));
-    o[6] = q1.y; o[7] = q1.z; o[8] = q1.w;
+    const V2 rel = ego_relative(ex, ey, einv, q0.x, q0.y);
+    o[0] = rel.x; o[1] = rel.y; o[2] = q1.x; o[3] = q1.y;
+    o[4] = type == ET_StopSign ? 1.f : 0.1f;  // the z scale of the road entity (scene.cpp put_road)
+    o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0.z, q0.w)));
+    o[6] = (float)type; o[7] = q1.z; o[8] = (float)map_type;
 }
 
 template <int A_T>
@@ -455,10 +457,11 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     __shared__ __attribute__((aligned(16))) float s_rows[RB * 9];
     const size_t rows = (size_t)d.W * A_T * K;
     const size_t base = (size_t)blockIdx.x * RB;
-    // everything a row needs besides the road itself is requested at once (one round trip, not a chain of them)
+    // the agent's header (pose, count, first road: written by the selection kernel) and the slot's road index come in one
+    // round trip, the road's 32-byte record in a second one
     bool on[U], in[U];
     int r[U];
-    float ex[U], ey[U], ew[U], ez[U];
+    float4 pose[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const size_t p = base + threadIdx.x + (size_t)u * 256;
@@ -466,22 +469,19 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
         const size_t pc = on[u] ? p : 0;
         const size_t wa = pc / K;
         const int s = (int)(pc - wa * K);
-        const int w = (int)(wa / A_T), a = (int)(wa - (size_t)w * A_T);
-        const int n = d.shape[w * 2 + 0];
-        const int cnt = d.sel_count[wa];
-        r[u] = d.road_off[w] + (int)d.sel_idx[pc];
-        ex[u] = d.px[wa]; ey[u] = d.py[wa]; ew[u] = d.qw[wa]; ez[u] = d.qz[wa];
-        on[u] = on[u] && a < n;  // rows of padding agents are written at reset (k_init_padding_rows)
+        pose[u] = d.sel_hdr[wa * 2];
+        const float4 meta = d.sel_hdr[wa * 2 + 1];
+        const int cnt = __float_as_int(meta.x);
+        r[u] = __float_as_int(meta.y) + (int)d.sel_idx[pc];
+        on[u] = on[u] && cnt >= 0;  // rows of padding agents are written at reset (k_init_padding_rows)
         in[u] = s < cnt;
-        if (!in[u]) r[u] = d.road_off[w];
+        if (!in[u]) r[u] = 0;
     }
-    float2 xy[U];
     float4 q0[U], q1[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        xy[u] = d.road_xy[r[u]];
-        q0[u] = d.road_aux[(size_t)r[u] * 2];
-        q1[u] = d.road_aux[(size_t)r[u] * 2 + 1];
+        q0[u] = d.road_rec[(size_t)r[u] * 2];
+        q1[u] = d.road_rec[(size_t)r[u] * 2 + 1];
     }
     // The block's rows are assembled in LDS (row stride 9 floats: conflict-free) and leave as whole 16-byte pieces in
     // row-major order, one piece per thread and pass; rows that must not be written (padding agents, beyond the
@@ -492,8 +492,8 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     for (int u = 0; u < U; u++) {
         const int lr = threadIdx.x + u * 256;
         s_on[lr] = on[u] ? 1 : 0;
-        road_row(s_rows + lr * 9, in[u], d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST, ex[u], ey[u], ew[u], ez[u], xy[u], q0[u],
-                 q1[u]);
+        road_row(s_rows + lr * 9, in[u], d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST, pose[u].x, pose[u].y, pose[u].z, pose[u].w,
+                 q0[u], q1[u]);
     }
     __syncthreads();
     float *out = d.agent_map + base * 9;  // base * 36 bytes: 16-byte aligned (RB * 36 is a multiple of 16)
@@ -513,17 +513,21 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
 }
 
 // Selection hand-over from a workgroup that holds agents a0 .. a0+na-1 of world w as columns: idx_of(col, s) is the road
-// index in slot s, count_of(col) the number of selected slots.  Consecutive threads store consecutive u16.
-template <int A_T, typename IdxOf, typename CountOf>
-__device__ __forceinline__ void store_selection(const DevSim &d, int w, int a0, int na, IdxOf idx_of, CountOf count_of, int tid,
-                                                int nthreads) {
+// index in slot s.  Consecutive threads store consecutive u16.  The agents' headers are written by their own lanes
+// (write_header).
+template <int A_T, typename IdxOf>
+__device__ __forceinline__ void store_selection(const DevSim &d, int w, int a0, int na, IdxOf idx_of, int tid, int nthreads) {
     const size_t wa0 = (size_t)w * A_T + a0;
     unsigned short *dst = d.sel_idx + wa0 * K;
     for (int q = tid; q < na * K; q += nthreads) {
         const int col = q / K, sl = q - col * K;
         dst[q] = (unsigned short)idx_of(col, sl);
     }
-    for (int col = tid; col < na; col += nthreads) d.sel_count[wa0 + col] = count_of(col);
+}
+// what k_map_rows needs to know about agent i besides its slots: pose (qz, not its inverse), row count, first road of the world
+__device__ __forceinline__ void write_header(const DevSim &d, size_t i, float ex, float ey, float qw, float qz, int count, int road0) {
+    d.sel_hdr[i * 2] = make_float4(ex, ey, qw, qz);
+    d.sel_hdr[i * 2 + 1] = make_float4(__int_as_float(count), __int_as_float(road0), 0.f, 0.f);
 }
 
 // ---- reference row order: one wave per AW agent slots of a world, G = 64 / AW lanes per agent ----
@@ -725,13 +729,10 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
         }
     }
     // ---- hand the selection to k_map_rows ----
-    int *s_count = reinterpret_cast<int *>(s_ring);  // [AW]
     wave_sync();
-    if (owner) s_count[col] = live ? min(count, K) : 0;
-    wave_sync();
+    if (owner && live) write_header(d, i, ex, ey, iw, -iz, min(count, K), r0);
     STAMP(t_w0);
-    store_selection<A_T>(d, w, a0, min(AW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; },
-                         [&](int c) -> int { return s_count[c]; }, lane, 64);
+    store_selection<A_T>(d, w, a0, min(AW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; }, lane, 64);
 #ifdef GD_STAMPS
     if (lane == 0 && blockIdx.x < 8192) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
 
     __shared__ float s_ckey[NW][CAP];
     __shared__ unsigned short s_cidx[NW][CAP];
-    __shared__ unsigned int s_bits[NW][BMW];
+    __shared__ __attribute__((aligned(16))) unsigned int s_bits[NW][BMW];
     __shared__ unsigned short s_sel[NW][K];
     float *ckey = s_ckey[wave];
     unsigned short *cidx = s_cidx[wave];
@@ -955,8 +956,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                     count = nin;
                 } else {
                     // the K-th smallest key T: largest T with count(key < T) < K.  The candidates' key bits sit in
-                    // registers (lane l holds candidates l, l + 64, ...); three probes per pass, counted with ballots
-                    // (scalar popcounts: no cross-lane traffic), so the interval shrinks four-fold per pass.
+                    // registers (lane l holds candidates l, l + 64, ...).
                     constexpr int KR = CAP / 64;
                     unsigned int kb[KR];
 #pragma unroll
@@ -970,24 +970,100 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                         return c;
                     };
                     // T lies in [floor_key, bound]: count(key < floor_key) < K (fewer than K roads can be that close), and
-                    // every candidate is <= bound
-                    unsigned int lo = __float_as_uint(floor_key), hi = __float_as_uint(bound);
-                    while (lo < hi) {
-                        const unsigned int step = (hi - lo + 3u) / 4u;  // >= 1
-                        const unsigned int p1 = lo + step, p2 = min(hi, p1 + step), p3 = min(hi, p2 + step);
-                        int c1 = 0, c2 = 0, c3 = 0;
+                    // every candidate is <= bound.  A 256-bucket histogram over that interval (bucket = a monotone function of
+                    // the key, LDS atomics on the still-empty bitmap words) names the bucket that holds T and how many keys lie
+                    // below it; T is then the m-th smallest key of that bucket, found by stepping through the bucket's distinct
+                    // values (usually one or two).  The search on the key bits further down is the fall-back.
+                    unsigned int lo = 0u;
+                    bool found = false;
+                    {
+                        unsigned int *hist = bits;  // words 0..255: zero now, zeroed again before the bitmap is used
+                        const float span = bound - floor_key;
+                        const float scale = span > 0.f ? 256.f / span : 0.f;
+                        auto bucket_of = [&](unsigned int kbits) -> int {
+                            const float t = (__uint_as_float(kbits) - floor_key) * scale;
+                            return min(255, max(0, (int)t));
+                        };
+                        int bk[KR];
 #pragma unroll
                         for (int u = 0; u < KR; u++) {
-                            if (u < nu) {
-                                c1 += __popcll(__ballot(kb[u] < p1));
-                                c2 += __popcll(__ballot(kb[u] < p2));
-                                c3 += __popcll(__ballot(kb[u] < p3));
+                            bk[u] = -1;
+                            if (u < nu && u * 64 + lane < nin) {
+                                bk[u] = bucket_of(kb[u]);
+                                atomicAdd(&hist[bk[u]], 1u);
                             }
                         }
-                        if (c3 < K) lo = p3;
-                        else if (c2 < K) { lo = p2; hi = p3 - 1u; }
-                        else if (c1 < K) { lo = p1; hi = p2 - 1u; }
-                        else hi = p1 - 1u;
+                        wave_sync();
+                        // lane l owns buckets 4l .. 4l + 3; inclusive prefix over the lanes (DPP), the lane where it crosses K
+                        const uint4 h = reinterpret_cast<const uint4 *>(hist)[lane];
+                        const int own = (int)(h.x + h.y + h.z + h.w);
+                        int incl = own;
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+                        const int excl = incl - own;
+                        reinterpret_cast<uint4 *>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
+                        int jb = 0, before = excl;  // this lane's answer if the crossing is in its four buckets
+                        if (before + (int)h.x < K) { before += (int)h.x; jb = 1;
+                            if (before + (int)h.y < K) { before += (int)h.y; jb = 2;
+                                if (before + (int)h.z < K) { before += (int)h.z; jb = 3; } } }
+                        const unsigned long long cross = __ballot(excl < K && incl >= K);  // exactly one lane: nin >= K
+                        const int L = __ffsll((long long)cross) - 1;
+                        const int bucket = 4 * L + __builtin_amdgcn_readlane(jb, L);
+                        const int m = K - __builtin_amdgcn_readlane(before, L);  // T is the m-th smallest key of the bucket, m >= 1
+                        unsigned int inb = 0u;
+#pragma unroll
+                        for (int u = 0; u < KR; u++) inb |= (bk[u] == bucket ? 1u : 0u) << u;
+                        unsigned int prev = 0u;
+                        bool first = true;
+                        int acc = 0;
+                        for (int it = 0; it < 48 && cross != 0ull; it++) {
+                            unsigned int cand = 0xffffffffu;
+#pragma unroll
+                            for (int u = 0; u < KR; u++)
+                                if (u < nu && ((inb >> u) & 1u) && (first || kb[u] > prev)) cand = min(cand, kb[u]);
+                            cand = min(cand, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)cand, 0x111, 0xf, 0xf, false));
+                            cand = min(cand, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)cand, 0x112, 0xf, 0xf, false));
+                            cand = min(cand, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)cand, 0x114, 0xf, 0xf, false));
+                            cand = min(cand, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)cand, 0x118, 0xf, 0xf, false));
+                            cand = min(cand, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)cand, 0x142, 0xa, 0xf, false));
+                            cand = min(cand, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)cand, 0x143, 0xc, 0xf, false));
+                            cand = (unsigned int)__builtin_amdgcn_readlane((int)cand, 63);  // the smallest value of the bucket above prev
+                            if (cand == 0xffffffffu) break;
+                            int c = 0;
+#pragma unroll
+                            for (int u = 0; u < KR; u++)
+                                if (u < nu) c += __popcll(__ballot(((inb >> u) & 1u) && kb[u] == cand));
+                            acc += c;
+                            if (acc >= m) { lo = cand; found = true; break; }
+                            prev = cand;
+                            first = false;
+                        }
+                        wave_sync();  // the histogram words are zero again before anything is marked
+                    }
+                    if (!found) {
+                        unsigned int hi = __float_as_uint(bound);
+                        lo = __float_as_uint(floor_key);
+                        while (lo < hi) {
+                            const unsigned int step = (hi - lo + 3u) / 4u;  // >= 1
+                            const unsigned int p1 = lo + step, p2 = min(hi, p1 + step), p3 = min(hi, p2 + step);
+                            int c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+                            for (int u = 0; u < KR; u++) {
+                                if (u < nu) {
+                                    c1 += __popcll(__ballot(kb[u] < p1));
+                                    c2 += __popcll(__ballot(kb[u] < p2));
+                                    c3 += __popcll(__ballot(kb[u] < p3));
+                                }
+                            }
+                            if (c3 < K) lo = p3;
+                            else if (c2 < K) { lo = p2; hi = p3 - 1u; }
+                            else if (c1 < K) { lo = p1; hi = p2 - 1u; }
+                            else hi = p1 - 1u;
+                        }
                     }
                     // everything below T, then the lowest road indices among the ties at T
                     const int less = count_below(lo);
@@ -1043,7 +1119,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         count = min(count, K);
         if (lane == 0) {
             d.knn_prev[i] = make_float4(ex, ey, kth, 0.f);
-            if (!FUSE) d.sel_count[i] = count;
+            if (!FUSE) write_header(d, i, ex, ey, iw, -iz, count, r0);
         }
         wave_sync();
         if (!FUSE) continue;  // k_map_rows writes the rows
@@ -1052,15 +1128,13 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         // workgroup is resident at once the separate, fully occupied k_map_rows is the faster write-out (launch_map_obs) ----
         constexpr int NP = (K + 63) / 64;
         static_assert(K % 4 == 0 && S::CAP >= 64 * 9, "whole 16-byte pieces; the staging block fits the key buffer");
-        float2 xy[NP];
         float4 q0[NP], q1[NP];
 #pragma unroll
         for (int p = 0; p < NP; p++) {  // every gather of the agent requested at once
             const int sl = p * 64 + lane;
             const int r = r0 + (sl < count ? (int)out[sl] : 0);
-            xy[p] = d.road_xy[r];
-            q0[p] = d.road_aux[(size_t)r * 2];
-            q1[p] = d.road_aux[(size_t)r * 2 + 1];
+            q0[p] = d.road_rec[(size_t)r * 2];
+            q1[p] = d.road_rec[(size_t)r * 2 + 1];
         }
         // 64 rows at a time are laid out in LDS (the candidate keys' buffer is free now) and leave as whole 16-byte pieces
         // of one contiguous block: an agent's rows start at a multiple of 7200 bytes and 64 rows are 2304, both multiples of 16
@@ -1070,7 +1144,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const int sl = p * 64 + lane;
-            road_row(stage + lane * 9, sl < count, knn, ex, ey, iw, -iz, xy[p], q0[p], q1[p]);
+            road_row(stage + lane * 9, sl < count, knn, ex, ey, iw, -iz, q0[p], q1[p]);
             wave_sync();
             const int pieces = min(64, K - p * 64) * 9 / 4;
             for (int q = lane; q < pieces; q += 64)
