@@ -56,7 +56,7 @@ constexpr int K = GD_MAP_OBS_K;
 #define GD_TRIG_NUM 4  // eighths of the live lanes that must be idle before the next chunk is scanned
 #endif
 #ifndef GD_ROWS_PER_THREAD
-#define GD_ROWS_PER_THREAD 2
+#define GD_ROWS_PER_THREAD 4
 #endif
 #ifndef GD_MAP_OBS_AW
 #define GD_MAP_OBS_AW 32
