@@ -418,32 +418,50 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         ao[13] = (float)s_id[a];
     }
 
-    // ---- collectPartnerObsSystem, :188-240.  One thread per (ego, slot) row so that a wave
-    // writes 64 consecutive 36-byte rows. ----
+    // ---- collectPartnerObsSystem, :188-240.  One thread per (ego, slot) row; a chunk of STEP_THREADS consecutive 36-byte rows
+    // is assembled in LDS (row stride 9 floats: conflict-free) and leaves as whole 16-byte pieces with streaming stores
+    // (a world's block starts at a multiple of 16 bytes and so does every chunk; only the piece that straddles the end
+    // of the live egos' rows goes element by element). ----
     if (!d.p.disableClassicalObs) {
+        __shared__ __attribute__((aligned(16))) float s_rows[STEP_THREADS * 9];
         const int rows = n * (A_T - 1);
         float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
-        for (int p = a; p < rows; p += STEP_THREADS) {
-            const int ego = p / (A_T - 1), k = p - ego * (A_T - 1);
-            float *o = base + (size_t)p * 9;
-            if (k >= n - 1) {  // zero_nonexist(): id -2
-                o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -2.f;
-                continue;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (int p0 = 0; p0 < rows; p0 += STEP_THREADS) {
+            const int p = p0 + a;
+            if (p < rows) {
+                const int ego = p / (A_T - 1), k = p - ego * (A_T - 1);
+                float *o = s_rows + a * 9;
+                if (k >= n - 1) {  // zero_nonexist(): id -2
+                    o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -2.f;
+                } else {
+                    const int j = k < ego ? k : k + 1;  // OtherAgents order, src/level_gen.cpp:450-464
+                    const Quat ego_inv = quat_inv(quat_from_wz(s_qw[ego], s_qz[ego]));
+                    const V3 r = quat_rotate(ego_inv, V3{s_px[j] - s_px[ego], s_py[j] - s_py[ego], 0.f});
+                    if (len_2(r.x, r.y) > d.p.observationRadius) {  // zero(): id -1
+                        o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -1.f;
+                    } else {
+                        const float heading = quat_to_yaw_row(quat_mul(ego_inv, quat_from_wz(s_qw[j], s_qz[j])));
+                        o[0] = s_speed[j];
+                        o[1] = r.x; o[2] = r.y;
+                        o[3] = heading;
+                        o[4] = s_len[j]; o[5] = s_wid[j]; o[6] = s_hgt[j];
+                        o[7] = (float)s_etype[j];
+                        o[8] = (float)s_id[j];
+                    }
+                }
             }
-            const int j = k < ego ? k : k + 1;  // OtherAgents order, src/level_gen.cpp:450-464
-            const Quat ego_inv = quat_inv(quat_from_wz(s_qw[ego], s_qz[ego]));
-            const V3 r = quat_rotate(ego_inv, V3{s_px[j] - s_px[ego], s_py[j] - s_py[ego], 0.f});
-            if (len_2(r.x, r.y) > d.p.observationRadius) {  // zero(): id -1
-                o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -1.f;
-            } else {
-                const float heading = quat_to_yaw_row(quat_mul(ego_inv, quat_from_wz(s_qw[j], s_qz[j])));
-                o[0] = s_speed[j];
-                o[1] = r.x; o[2] = r.y;
-                o[3] = heading;
-                o[4] = s_len[j]; o[5] = s_wid[j]; o[6] = s_hgt[j];
-                o[7] = (float)s_etype[j];
-                o[8] = (float)s_id[j];
+            __syncthreads();
+            const int nf = min(STEP_THREADS, rows - p0) * 9;  // floats of this chunk
+            float *out = base + (size_t)p0 * 9;
+            for (int q = a; q * 4 < nf; q += STEP_THREADS) {
+                if (q * 4 + 4 <= nf) {
+                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + q * 4));
+                } else {
+                    for (int e = q * 4; e < nf; e++) out[e] = s_rows[e];
+                }
             }
+            __syncthreads();
         }
     }
 }
