@@ -475,13 +475,19 @@ struct gd_sim {
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.road_off), road_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
         upload_road_grids();
         {
-            // longest-first launch order of the road kernel: its time per world grows with the road count
+            // longest-first launch order of the road kernel: its time per world grows with the road count (the kernel
+            // re-sorts by measured cycles after every launch; this is the order of the first one)
+            const int parts = d.A / GD_MAP_OBS_AW;
             std::vector<int32_t> order(W);
             for (int w = 0; w < W; w++) order[w] = w;
             std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
                 return road_off[x + 1] - road_off[x] > road_off[y + 1] - road_off[y];
             });
-            HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.world_order), order.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
+            std::vector<int32_t> waves(static_cast<size_t>(W) * parts);
+            for (int k = 0; k < W; k++)
+                for (int q = 0; q < parts; q++) waves[static_cast<size_t>(k) * parts + q] = order[k] * parts + q;
+            HIP_CHECK(hipMemcpy(d.wave_order, waves.data(), sizeof(int32_t) * waves.size(), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemset(d.wave_cost, 0, sizeof(uint32_t) * waves.size()));
         }
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.box_off), box_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
         d.road_xy = static_cast<const float2 *>(d_road_xy);
@@ -750,7 +756,8 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.any_reset = s->alloc_internal<int32_t>(1);
         d.gate_any = 0;
         d.road_off = s->alloc_internal<int32_t>(W + 1);
-        d.world_order = s->alloc_internal<int32_t>(W);
+        d.wave_order = s->alloc_internal<int32_t>(static_cast<size_t>(W) * (A / GD_MAP_OBS_AW));
+        d.wave_cost = s->alloc_internal<uint32_t>(static_cast<size_t>(W) * (A / GD_MAP_OBS_AW));
         d.box_off = s->alloc_internal<int32_t>(W + 1);
         d.grid = s->alloc_internal<gd::GridHdr>(W);
         d.rgrid = s->alloc_internal<gd::GridHdr>(W);

@@ -6,6 +6,10 @@
 
 #include "../../include/gpudrive_amd.h"
 
+#ifndef GD_MAP_OBS_AW
+#define GD_MAP_OBS_AW 32  // agents per workgroup (= wave) of the reference-order road kernel: 16, 32 or 64
+#endif
+
 namespace gd {
 
 // the first four are the timed kernels of gd_kernel_timing_read
@@ -53,7 +57,9 @@ struct DevSim {
                            // every workgroup returns at once unless *any_reset is set
     // roads
     const int32_t *road_off;  // [W+1]
-    const int32_t *world_order;  // [W] worlds by decreasing road count: the road kernel starts its longest workgroups first
+    int32_t *wave_order;   // [W * A / GD_MAP_OBS_AW] workgroups of the reference-order road kernel (world * A/AW + part) in launch order: longest first,
+                           // by road count at load time, then by the cycles each one took in the previous launch (k_order_waves)
+    uint32_t *wave_cost;   // [W * A / GD_MAP_OBS_AW] cycles of each of those workgroups in the last launch that ran them
     const float2 *road_xy;
     const float4 *road_aux;
     const float4 *road_rec;  // [roads][2] what a row of agent_roadmap_tensor needs, in 32 bytes: (x, y, qw, qz), (d0, d1, id, bits: type | (mapType + 1) << 8)

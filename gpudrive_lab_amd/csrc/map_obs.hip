@@ -58,9 +58,6 @@ constexpr int K = GD_MAP_OBS_K;
 #ifndef GD_ROWS_PER_THREAD
 #define GD_ROWS_PER_THREAD 4
 #endif
-#ifndef GD_MAP_OBS_AW
-#define GD_MAP_OBS_AW 32
-#endif
 constexpr int AW = GD_MAP_OBS_AW;  // agents (heap columns) per workgroup = per wave of the reference-order kernel
 constexpr int G = 64 / AW;         // lanes per agent: lane = sub * AW + column
 constexpr int SLOTS = K + 2;       // stored slots 1..K (the heap), K+1 and K+2 (sentinels); slot g is row g - 1
@@ -539,9 +536,11 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     const int lane = threadIdx.x;
     const int col = lane % AW, sub = lane / AW;
     const bool owner = sub == 0;
-    const int w = d.world_order[(int)blockIdx.x / BPW];  // longest worlds first
-    const int a0 = ((int)blockIdx.x % BPW) * AW;
+    const int slot = d.wave_order[blockIdx.x];  // longest workgroups first (k_order_waves)
+    const int w = slot / BPW;
+    const int a0 = (slot % BPW) * AW;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
+    const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
     const int n = d.shape[w * 2 + 0];
     if (a0 >= n) return;  // rows of padding agents are written at reset (k_init_padding_rows)
     const int r0 = d.road_off[w];
@@ -733,6 +732,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     if (owner && live) write_header(d, i, ex, ey, iw, -iz, min(count, K), r0);
     STAMP(t_w0);
     store_selection<A_T>(d, w, a0, min(AW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; }, lane, 64);
+    if (lane == 0) d.wave_cost[slot] = (unsigned int)min(__builtin_amdgcn_s_memtime() - t_launch, 0xffffffffull);
 #ifdef GD_STAMPS
     if (lane == 0 && blockIdx.x < 8192) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -741,6 +741,36 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
         o[6] = st_wscan; o[7] = st_wround;
     }
 #endif
+}
+
+// ---- launch order of the next k_map_obs ----
+// The LDS lets 1024 of its workgroups run at a time and a launch has 2048 or more, whose durations differ by +-20 % with
+// the number of heap inserts their agents need; in index order the launch ends when an unlucky slot finishes its second
+// long workgroup (measured: 18 % above the balanced time on the bench scene).  The agents move a fraction of a metre per
+// step, so a workgroup's cycles in this launch predict the next: the workgroups are re-sorted longest first (counting
+// sort over 256 cost buckets, one workgroup; the order inside a bucket is whatever the atomics give -- it only ever
+// changes WHEN a workgroup runs, never what it computes).
+__global__ __launch_bounds__(1024) void k_order_waves(DevSim d, int count) {
+    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged, nothing ran
+    __shared__ unsigned int s_max, s_cnt[256], s_off[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) s_cnt[tid] = 0u;
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    unsigned int m = 0u;
+    for (int i = tid; i < count; i += 1024) m = max(m, d.wave_cost[i]);
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const unsigned long long mx = max(s_max, 1u);
+    auto bucket = [&](unsigned int c) -> int { return 255 - (int)min(255ull, (unsigned long long)c * 255ull / mx); };  // costliest first
+    for (int i = tid; i < count; i += 1024) atomicAdd(&s_cnt[bucket(d.wave_cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int run = 0u;
+        for (int b = 0; b < 256; b++) { s_off[b] = run; run += s_cnt[b]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < count; i += 1024) d.wave_order[atomicAdd(&s_off[bucket(d.wave_cost[i])], 1u)] = i;
 }
 
 // ---- set-order mode (gd_config.knn_order = GD_KNN_SET_ORDER) ----
@@ -1170,6 +1200,7 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         const dim3 grid(d.W * (d.A / AW));
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64>), grid, dim3(64), 0, st, d);
         else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_order_waves, dim3(1), dim3(1024), 0, st, d, (int)grid.x);
     }
     const size_t rows = (size_t)d.W * d.A * K;
     const dim3 rgrid((unsigned int)((rows + 256 * GD_ROWS_PER_THREAD - 1) / (256 * GD_ROWS_PER_THREAD)));

@@ -26,6 +26,7 @@ buf = (ctypes.c_ulonglong * (8 * n))()
 rc = lib.gd_debug_read_stamps(buf, n)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.float64)
 a = a[a[:, 0] > 0]
+np.save("gpurun_out/stamps_%s.npy" % wl, a)  # row = workgroup in launch order; tools/dispatch_sim.py replays the dispatch
 names = ["total", "init(fill+make_heap)", "scan", "drain", "rounds", "scans", "vmcnt wait at scan", "vmcnt wait at round top"]
 print("workload", wl, "workgroups", len(a), "rc", rc)
 for i, nm in enumerate(names):
