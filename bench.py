@@ -192,7 +192,7 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
             tkey = workload if args.knn_order == 0 else ("set_cfg3" if workload == "cfg3" else None)
         with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
             tj = json.load(fh)
-        if tj.get("source_stamp") == source_stamp() and args.worlds == 1024 and args.agents == 64:
+        if tj.get("source_stamp") == source_stamp() and args.worlds == (4096 if workload == "cfg3" else 1024) and args.agents == 64:
             traffic = tj.get(tkey, {}).get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
