@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     }
     // A chunk of 32 roads is one coalesced 256-byte load: lane j holds float j of (x0, y0, x1, y1, ...).  It is
     // requested long before it is used; a lane picks the (x, y) of its PL roads out of the register with
-    // ds_bpermute (the LDS crossbar, no LDS memory).  Road t of a chunk belongs to lane sub = t % G of every agent.
+    // ds_bpermute (the LDS crossbar, no LDS memory).  Lane `sub` of an agent takes roads sub * PL .. sub * PL + PL - 1 of a chunk.
     // Reads up to 256 roads past the world's last one stay inside the array (the next world's roads or the pad).
     const float *rf = reinterpret_cast<const float *>(rxy);
     auto load_chunk = [&](int first_road) -> float { return rf[first_road * 2 + lane]; };
@@ -643,14 +643,25 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
                 const int base = K + head * C;
                 const int cur = __float_as_int(pre);
                 const float thr = live ? top.tk[1] * margin : -1.f;
-                unsigned int part = 0;
+                // every (x, y) of the lane's roads is requested before the first one is used (one LDS-crossbar latency instead
+                // of one per pair); the in-range bit of a road is the sign of d2 - thr (no compare -> mask -> select chain) and
+                // is shifted in with one v_alignbit.  Lane `sub` takes roads sub * PL .. sub * PL + PL - 1 of the chunk.
+                float2 xy[PL];
 #pragma unroll
                 for (int k = 0; k < PL; k++) {
-                    const float2 xy = road_of(cur, k);
-                    const float dx = xy.x - ex, dy = xy.y - ey;
-                    const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                    part |= (d2 < thr ? 1u : 0u) << (k * G + sub);
+                    const int t = sub * PL + k;
+                    xy[k] = make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(8 * t, cur)),
+                                        __int_as_float(__builtin_amdgcn_ds_bpermute(8 * t + 4, cur)));
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned int q = 0;
+#pragma unroll
+                for (int k = PL - 1; k >= 0; k--) {
+                    const float dx = xy[k].x - ex, dy = xy[k].y - ey;
+                    const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                    q = __builtin_amdgcn_alignbit(q, __float_as_uint(d2 - thr), 31);  // (q << 1) | sign(d2 - thr): d2 < thr, both finite
+                }
+                const unsigned int part = q << (sub * PL);
                 pre = load_chunk(base + 2 * C);
                 unsigned int wd = agent_or(part);
                 const int tn = R - base;
