@@ -97,6 +97,8 @@ struct gd_sim {
     std::vector<int32_t> deleted;  // host mirror [W][A]
     // per-world host road data (kept to repack the CSR on set_maps / deleteAgents)
     std::vector<std::vector<float>> w_xy, w_aux;
+    std::vector<int> w_agents;  // live agents per world (shape[w][0])
+    int cu_count = 256;
     std::vector<std::vector<gd::RoadBox>> w_boxes;
     std::vector<gd::GridHdr> w_grid;
     std::vector<std::vector<int32_t>> w_cell_off, w_cell_items;
@@ -200,6 +202,24 @@ struct gd_sim {
             (void)hipGraphExecDestroy(step_graph);
             step_graph = nullptr;
         }
+    }
+
+    // Set-order road kernel: how the agents are dealt to workgroups and which of its two equivalent write-outs runs
+    // (map_obs.hip, launch_map_obs).  Neither changes a result.  Measured at 1024 x 64 (road observation, us):
+    //   full worlds (synthetic)   16 agents per wave + row kernel 315,  2 per wave + row kernel 306,  2 per wave + fused 322
+    //   ragged worlds (Waymo)     16 + row kernel 104,                   2 + row kernel 91,            2 + fused 81
+    //   4096 ragged worlds        16 + fused 278,                        2 + fused 293,                2 + row kernel 439
+    // so: many generations of workgroups -> big workgroups, rows stored by the selecting wave; otherwise small
+    // workgroups (a 64-agent world no longer holds its CU four times as long as a 15-agent one), fused when the batch is
+    // ragged.  GPUDRIVE_SET_FUSED_ROWS=0|1 and GPUDRIVE_SET_AGENTS_PER_WAVE=n pin them (the tests run the combinations).
+    void choose_set_schedule() {
+        bool ragged = false;
+        for (int w = 0; w < W; w++) ragged = ragged || w_agents[w] < A;
+        const bool many = W >= 8 * cu_count;
+        d.set_apw = many ? 16 : 2;
+        d.set_fused_rows = (many || ragged) ? 1 : 0;
+        if (const char *e = std::getenv("GPUDRIVE_SET_FUSED_ROWS")) d.set_fused_rows = std::atoi(e) != 0 ? 1 : 0;
+        if (const char *e = std::getenv("GPUDRIVE_SET_AGENTS_PER_WAVE")) d.set_apw = std::min(32, std::max(1, std::atoi(e)));
     }
 
     void step() {
@@ -383,6 +403,7 @@ struct gd_sim {
             st.shape.push_back(hw->num_agents);
             st.shape.push_back(hw->num_roads);
             w_xy[w] = hw->road_xy;
+            w_agents[w] = hw->num_agents;
             w_aux[w] = hw->road_aux;
             w_boxes[w] = hw->boxes;
             w_grid[w] = gd::GridHdr{hw->grid_ox, hw->grid_oy, 1.f / hw->grid_cell, hw->grid_nx, hw->grid_ny, 0, 0, 0};
@@ -495,6 +516,7 @@ struct gd_sim {
         d.road_rec = static_cast<const float4 *>(d_road_rec);
         d.boxes = static_cast<const float4 *>(d_boxes);
         HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
+        choose_set_schedule();
         launch(gd::KERNEL_PADDING, false);
     }
 
@@ -676,6 +698,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         }
         s->deleted.assign(static_cast<size_t>(W) * A, -1);  // src/sim.cpp:1003-1006
         s->w_xy.resize(W);
+        s->w_agents.assign(W, 0);
         s->w_aux.resize(W);
         s->w_boxes.resize(W);
         s->w_grid.resize(W);
@@ -701,13 +724,9 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.p = *params;
         d.knn_order = cfg->knn_order;
         {
-            // Set-order mode has two equivalent write-outs (map_obs.hip, launch_map_obs): rows stored by the selecting wave
-            // pay off once the worlds outnumber the resident workgroups (4 per CU) at least twice.  The choice never changes
-            // a result; GPUDRIVE_SET_FUSED_ROWS=0|1 pins it (the tests run both on small batches).
-            int cus = 256;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
-            d.set_fused_rows = W >= 8 * cus ? 1 : 0;
-            if (const char *e = std::getenv("GPUDRIVE_SET_FUSED_ROWS")) d.set_fused_rows = std::atoi(e) != 0 ? 1 : 0;
+            (void)hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
+            d.set_fused_rows = 0;  // chosen with the worlds (rebuild_worlds -> choose_set_schedule)
+            d.set_apw = 16;
         }
         d.lidar_half_angle = cfg->lidar_half_angle;
         {

@@ -33,7 +33,8 @@ struct GridHdr {
 struct DevSim {
     int W, A;
     int knn_order;    // GD_KNN_*
-    int set_fused_rows;  // set-order mode: the selection kernel writes the rows itself (several generations of workgroups)
+    int set_fused_rows;  // set-order mode: the selection kernel writes the rows itself (several generations of workgroups, ragged batches)
+    int set_apw;         // set-order mode: agents per wave (a workgroup of 4 waves takes 4 * set_apw consecutive agents of a world)
     float lidar_half_angle;  // 0 -> pi/3 (reference consts::lidarAngle)
     float radius_key_max;    // largest fp32 k with sqrtf(k) <= observationRadius (radiusFilter on squared keys)
     gd_params p;

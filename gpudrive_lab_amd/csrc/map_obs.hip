@@ -913,7 +913,9 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
     const float2 *cxy = d.rcell_xy + g.item_base;
     const float kmax = d.radius_key_max;
 
-    for (int a = wave; a < n; a += NW) {  // wave-uniform
+    // a workgroup takes NW * set_apw consecutive agents of its world (blockIdx.y), each wave set_apw of them
+    const int a_first = (int)blockIdx.y * (NW * d.set_apw), a_end = min(n, a_first + NW * d.set_apw);
+    for (int a = a_first + wave; a < a_end; a += NW) {  // wave-uniform
         const size_t i = (size_t)w * A_T + a;
         const float ex = d.px[i], ey = d.py[i];
         const float iw = d.qw[i], iz = -d.qz[i];  // the INVERSE rotation
@@ -1199,7 +1201,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
 
 void launch_map_obs(const DevSim &d, hipStream_t st) {
     if (d.knn_order == GD_KNN_SET_ORDER) {
-        const dim3 grid(d.W);
+        const dim3 grid(d.W, (d.A + 4 * d.set_apw - 1) / (4 * d.set_apw));
         if (d.set_fused_rows) {
             if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4, true>), grid, dim3(256), 0, st, d);
             else hipLaunchKernelGGL((k_map_obs_set<128, 4, true>), grid, dim3(256), 0, st, d);

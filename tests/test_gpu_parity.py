@@ -124,13 +124,15 @@ SET_ORDER = [
 ]
 
 
-@pytest.mark.parametrize("rows", ["rows_kernel", "rows_fused"])
+@pytest.mark.parametrize("rows", ["rows_kernel", "rows_fused", "rows_fused_16_per_wave", "rows_kernel_16_per_wave"])
 @pytest.mark.parametrize("name,scenes,A,steps,kw", SET_ORDER, ids=[c[0] for c in SET_ORDER])
 def test_set_order_mode_matches_reference_rows_as_a_set(oracle_mod, monkeypatch, name, scenes, A, steps, kw, rows):
     """gd_config.knn_order = GD_KNN_SET_ORDER: every other tensor identical, road rows equal to the
     oracle's as a set (the reference's order is a heap-history artefact).  Both write-outs of that mode
     (k_map_rows, and rows stored by the selecting wave: the engine picks by batch size) are run."""
-    monkeypatch.setenv("GPUDRIVE_SET_FUSED_ROWS", "1" if rows == "rows_fused" else "0")
+    monkeypatch.setenv("GPUDRIVE_SET_FUSED_ROWS", "1" if "fused" in rows else "0")
+    if "16_per_wave" in rows:  # the engine's choice for thousands of worlds
+        monkeypatch.setenv("GPUDRIVE_SET_AGENTS_PER_WAVE", "16")
     gpu = P.make_gpu_sim(scenes, max_agents=A, knn_order=1, **kw)
     orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=A, **kw)
     names = [n for n in P.OBS_TENSORS if n != "agent_roadmap_tensor"]
