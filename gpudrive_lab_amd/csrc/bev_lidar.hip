@@ -23,6 +23,9 @@ namespace {
 
 constexpr int K = GD_MAP_OBS_K;
 constexpr int RES = GD_BEV_RES;
+#ifndef GD_LIDAR_GROUP
+#define GD_LIDAR_GROUP 4  // agents per workgroup of k_lidar = one per wave (16 per workgroup: 350 us on the Waymo tiles, 8: 322, 4: 312)
+#endif
 #ifndef GD_BEV_BANDS
 #define GD_BEV_BANDS 4  // bands of 50 grid rows: 40,000 bytes of cells (measured: 4 bands 2.04 ms, 5 2.16, 8 2.42)
 #endif
@@ -80,10 +83,11 @@ template <int A_T, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(GD_BEV_WAVES_PER_SIMD, 8))) void k_bev(DevSim d) {
     constexpr int NWV = NT / 64;  // waves
     static_assert(NT >= 128 && NT % 64 == 0, "geometry");
-    const int a = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
+    // one workgroup per live agent (engine: live_list); rows of padding agents are never written (src/level_gen.cpp:308-336)
+    const int wa = d.live_list[blockIdx.x], tid = threadIdx.x;
+    const int w = wa / A_T, a = wa - w * A_T;
     const int n = d.shape[w * 2 + 0];
-    if (a >= n) return;  // rows of padding agents are never written (src/level_gen.cpp:308-336)
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = d.road_off[w];
     const int R = d.road_off[w + 1] - r0;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
     const float offs[3] = {0.5f, 0.1f, -0.1f};  // src/consts.hpp:42-44
 
     // blockIdx.y: a group of GROUP agents of the world (worlds with many agents get several workgroups)
-    constexpr int GROUP = 16;
+    constexpr int GROUP = GD_LIDAR_GROUP;
     const int a_end = min(n, (int)(blockIdx.y + 1) * GROUP);
     for (int a = blockIdx.y * GROUP + wave; a < a_end; a += 4) {
         const size_t i = (size_t)w * A_T + a;
@@ -497,14 +501,15 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
 }  // namespace
 
 void launch_bev(const DevSim &d, hipStream_t st) {
-    const dim3 grid(d.A, d.W);
+    if (d.live_count == 0) return;
+    const dim3 grid(d.live_count);
     constexpr int NT = 512;  // 8 waves x 25 grid rows (measured: 256 threads 3.5 ms, 512 3.1 ms, 640 5.4 ms)
     if (d.A == 64) hipLaunchKernelGGL((k_bev<64, NT>), grid, dim3(NT), 0, st, d);
     else hipLaunchKernelGGL((k_bev<128, NT>), grid, dim3(NT), 0, st, d);
 }
 
 void launch_lidar(const DevSim &d, hipStream_t st) {
-    const dim3 grid(d.W, d.A / 16);
+    const dim3 grid(d.W, d.A / GD_LIDAR_GROUP);
     if (d.A == 64) hipLaunchKernelGGL(k_lidar<64>, grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL(k_lidar<128>, grid, dim3(256), 0, st, d);
 }

@@ -517,6 +517,16 @@ struct gd_sim {
         d.boxes = static_cast<const float4 *>(d_boxes);
         HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
         choose_set_schedule();
+        {
+            // one BEV workgroup per LIVE agent: a workgroup that only finds out it has no agent still has to be given
+            // its 48 KB of LDS and eight waves first
+            std::vector<int32_t> live;
+            live.reserve(static_cast<size_t>(W) * A);
+            for (int w = 0; w < W; w++)
+                for (int a = 0; a < w_agents[w]; a++) live.push_back(w * A + a);
+            d.live_count = static_cast<int>(live.size());
+            if (!live.empty()) HIP_CHECK(hipMemcpy(d.live_list, live.data(), sizeof(int32_t) * live.size(), hipMemcpyHostToDevice));
+        }
         launch(gd::KERNEL_PADDING, false);
     }
 
@@ -775,6 +785,8 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.any_reset = s->alloc_internal<int32_t>(1);
         d.gate_any = 0;
         d.road_off = s->alloc_internal<int32_t>(W + 1);
+        d.live_list = s->alloc_internal<int32_t>(WA);
+        d.live_count = 0;
         d.wave_order = s->alloc_internal<int32_t>(static_cast<size_t>(W) * (A / GD_MAP_OBS_AW));
         d.wave_cost = s->alloc_internal<uint32_t>(static_cast<size_t>(W) * (A / GD_MAP_OBS_AW));
         d.box_off = s->alloc_internal<int32_t>(W + 1);
