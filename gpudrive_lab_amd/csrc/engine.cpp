@@ -522,10 +522,19 @@ struct gd_sim {
             // its 48 KB of LDS and eight waves first
             std::vector<int32_t> live;
             live.reserve(static_cast<size_t>(W) * A);
-            for (int w = 0; w < W; w++)
-                for (int a = 0; a < w_agents[w]; a++) live.push_back(w * A + a);
+            for (int a = 0; a < A; a++)  // agent-major: consecutive workgroups belong to different worlds
+                for (int w = 0; w < W; w++)
+                    if (a < w_agents[w]) live.push_back(w * A + a);
             d.live_count = static_cast<int>(live.size());
             if (!live.empty()) HIP_CHECK(hipMemcpy(d.live_list, live.data(), sizeof(int32_t) * live.size(), hipMemcpyHostToDevice));
+            // likewise the set-order road kernel's workgroups (4 waves x set_apw agents each)
+            std::vector<int32_t> groups;
+            const int per = 4 * d.set_apw;
+            for (int g = 0; g * per < A; g++)  // group-major: consecutive workgroups belong to different worlds
+                for (int w = 0; w < W; w++)
+                    if (g * per < w_agents[w]) groups.push_back(w << 8 | g);
+            d.set_group_count = static_cast<int>(groups.size());
+            if (!groups.empty()) HIP_CHECK(hipMemcpy(d.set_groups, groups.data(), sizeof(int32_t) * groups.size(), hipMemcpyHostToDevice));
         }
         launch(gd::KERNEL_PADDING, false);
     }
@@ -787,6 +796,8 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.road_off = s->alloc_internal<int32_t>(W + 1);
         d.live_list = s->alloc_internal<int32_t>(WA);
         d.live_count = 0;
+        d.set_groups = s->alloc_internal<int32_t>(WA);
+        d.set_group_count = 0;
         d.wave_order = s->alloc_internal<int32_t>(static_cast<size_t>(W) * (A / GD_MAP_OBS_AW));
         d.wave_cost = s->alloc_internal<uint32_t>(static_cast<size_t>(W) * (A / GD_MAP_OBS_AW));
         d.box_off = s->alloc_internal<int32_t>(W + 1);

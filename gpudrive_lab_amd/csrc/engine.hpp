@@ -34,8 +34,10 @@ struct DevSim {
     int W, A;
     int knn_order;    // GD_KNN_*
     int set_fused_rows;  // set-order mode: the selection kernel writes the rows itself (several generations of workgroups, ragged batches)
-    int32_t *live_list;  // [W * A] world * A + agent of every live agent, world-major (rebuilt with the worlds)
+    int32_t *live_list;  // [W * A] world * A + agent of every live agent, agent-major (rebuilt with the worlds)
     int live_count;
+    int32_t *set_groups;  // set-order kernel: (world << 8 | group) of every group of 4 * set_apw agent slots that holds a live agent
+    int set_group_count;
     int set_apw;         // set-order mode: agents per wave (a workgroup of 4 waves takes 4 * set_apw consecutive agents of a world)
     float lidar_half_angle;  // 0 -> pi/3 (reference consts::lidarAngle)
     float radius_key_max;    // largest fp32 k with sqrtf(k) <= observationRadius (radiusFilter on squared keys)

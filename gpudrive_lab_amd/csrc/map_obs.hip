@@ -890,8 +890,9 @@ template <int A_T, int NW, bool FUSE>
 __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
     using S = SetSel<A_T>;
     constexpr int CAP = S::CAP, BMW = S::BMW;
-    const int w = blockIdx.x, tid = threadIdx.x;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
+    const int wg = d.set_groups[blockIdx.x];  // only groups of agent slots that hold a live agent are launched
+    const int w = wg >> 8, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int n = d.shape[w * 2 + 0];
     const int r0 = d.road_off[w];
@@ -913,8 +914,8 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
     const float2 *cxy = d.rcell_xy + g.item_base;
     const float kmax = d.radius_key_max;
 
-    // a workgroup takes NW * set_apw consecutive agents of its world (blockIdx.y), each wave set_apw of them
-    const int a_first = (int)blockIdx.y * (NW * d.set_apw), a_end = min(n, a_first + NW * d.set_apw);
+    // a workgroup takes NW * set_apw consecutive agents of its world (set_groups), each wave set_apw of them
+    const int a_first = (wg & 255) * (NW * d.set_apw), a_end = min(n, a_first + NW * d.set_apw);
     for (int a = a_first + wave; a < a_end; a += NW) {  // wave-uniform
         const size_t i = (size_t)w * A_T + a;
         const float ex = d.px[i], ey = d.py[i];
@@ -1201,7 +1202,8 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
 
 void launch_map_obs(const DevSim &d, hipStream_t st) {
     if (d.knn_order == GD_KNN_SET_ORDER) {
-        const dim3 grid(d.W, (d.A + 4 * d.set_apw - 1) / (4 * d.set_apw));
+        if (d.set_group_count == 0) return;
+        const dim3 grid(d.set_group_count);
         if (d.set_fused_rows) {
             if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4, true>), grid, dim3(256), 0, st, d);
             else hipLaunchKernelGGL((k_map_obs_set<128, 4, true>), grid, dim3(256), 0, st, d);
