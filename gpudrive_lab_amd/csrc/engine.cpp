@@ -108,7 +108,7 @@ struct gd_sim {
     size_t rcell_cap = 0, ritem_cap = 0;
     void *d_rcell_off = nullptr, *d_rcell_items = nullptr, *d_rcell_xy = nullptr;
     size_t cell_cap = 0, item_cap = 0;
-    void *d_cell_off = nullptr, *d_cell_items = nullptr;
+    void *d_cell_off = nullptr, *d_cell_items = nullptr, *d_cell_hdr = nullptr;
     size_t road_cap = 0, box_cap = 0;
     void *d_road_xy = nullptr, *d_road_aux = nullptr, *d_road_rec = nullptr, *d_boxes = nullptr;
     // pinned flag staging ring
@@ -135,6 +135,7 @@ struct gd_sim {
         if (d_boxes) (void)hipFree(d_boxes);
         if (d_cell_off) (void)hipFree(d_cell_off);
         if (d_cell_items) (void)hipFree(d_cell_items);
+        if (d_cell_hdr) (void)hipFree(d_cell_hdr);
         if (d_rcell_off) (void)hipFree(d_rcell_off);
         if (d_rcell_items) (void)hipFree(d_rcell_items);
         if (d_rcell_xy) (void)hipFree(d_rcell_xy);
@@ -479,8 +480,10 @@ struct gd_sim {
             }
             if (nitem > item_cap) {
                 if (d_cell_items) (void)hipFree(d_cell_items);
+                if (d_cell_hdr) (void)hipFree(d_cell_hdr);
                 item_cap = nitem + nitem / 8 + 64;
                 HIP_CHECK(hipMalloc(&d_cell_items, item_cap * sizeof(int32_t)));
+                HIP_CHECK(hipMalloc(&d_cell_hdr, item_cap * sizeof(float) * 4));
             }
             std::vector<int32_t> co(ncell), ci(nitem);
             for (int w = 0; w < W; w++) {
@@ -489,9 +492,22 @@ struct gd_sim {
             }
             if (ncell) HIP_CHECK(hipMemcpy(d_cell_off, co.data(), ncell * sizeof(int32_t), hipMemcpyHostToDevice));
             if (nitem) HIP_CHECK(hipMemcpy(d_cell_items, ci.data(), nitem * sizeof(int32_t), hipMemcpyHostToDevice));
+            {
+                std::vector<float> ch(nitem * 4);
+                for (int w = 0; w < W; w++) {
+                    const std::vector<int32_t> &items = w_cell_items[w];
+                    for (size_t i = 0; i < items.size(); i++) {
+                        const gd::RoadBox &b = w_boxes[w][items[i]];
+                        float *o = &ch[(static_cast<size_t>(w_grid[w].item_base) + i) * 4];
+                        o[0] = b.cx; o[1] = b.cy; o[2] = b.radius; o[3] = b.type;
+                    }
+                }
+                if (nitem) HIP_CHECK(hipMemcpy(d_cell_hdr, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             HIP_CHECK(hipMemcpy(const_cast<gd::GridHdr *>(d.grid), w_grid.data(), sizeof(gd::GridHdr) * W, hipMemcpyHostToDevice));
             d.cell_off = static_cast<const int32_t *>(d_cell_off);
             d.cell_items = static_cast<const int32_t *>(d_cell_items);
+            d.cell_hdr = static_cast<const float4 *>(d_cell_hdr);
         }
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.road_off), road_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
         upload_road_grids();

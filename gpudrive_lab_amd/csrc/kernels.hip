@@ -338,9 +338,18 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
                     const int cell = (int)fy * gh.nx + (int)fx;
                     const int c0 = d.cell_off[gh.cell_base + cell], c1 = d.cell_off[gh.cell_base + cell + 1];
                     const int bbase = d.box_off[w];
-                    for (int c = c0 + part; c < c1; c += P) {
-                        const size_t r = (size_t)(bbase + d.cell_items[gh.item_base + c]);
-                        const float4 hdr = d.boxes[r * 5];
+                    // the cull reads (centre, radius, type) from the cell-ordered copy, one candidate ahead; only a box that
+                    // passes it is fetched through its index
+                    const float4 *chdr = d.cell_hdr + gh.item_base;
+                    const int32_t *citem = d.cell_items + gh.item_base;
+                    int c = c0 + part;
+                    float4 hdr_n = make_float4(0.f, 0.f, 0.f, 0.f);
+                    int item_n = 0;
+                    if (c < c1) { hdr_n = chdr[c]; item_n = citem[c]; }
+                    for (; c < c1; c += P) {
+                        const float4 hdr = hdr_n;
+                        const size_t r = (size_t)(bbase + item_n);
+                        if (c + P < c1) { hdr_n = chdr[c + P]; item_n = citem[c + P]; }
                         const int rtype = (int)hdr.w;
                         if (collision_pair_filtered(my_type, rtype)) continue;
                         const float dx = mx - hdr.x, dy = my - hdr.y;
