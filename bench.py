@@ -214,7 +214,10 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
         extra["k_world_step"] = dict(algorithmic_bytes_per_launch=b, achieved=b / (kt["k_world_step"]["avg_us"] * 1e-6) / 1e9,
                                      frac=b / (kt["k_world_step"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, unit="GB/s")
     res["other_rooflines"] = extra
-    res["engine"] = dict(graph_steps=sim.stat(0), plain_steps=sim.stat(1), graph_captures=sim.stat(2))
+    res["engine"] = dict(graph_steps=sim.stat(0), plain_steps=sim.stat(1), graph_captures=sim.stat(2),
+                         set_order_rows_fused=sim.stat(3), set_order_agents_per_wave=sim.stat(4),
+                         schedule_env={k: os.environ[k] for k in ("GPUDRIVE_NO_GRAPH", "GPUDRIVE_SET_FUSED_ROWS",
+                                                                   "GPUDRIVE_SET_AGENTS_PER_WAVE") if k in os.environ})
     # ---- BASELINE configs[3]: observation all-gather over RCCL, overlapped with the next step ----
     if world > 1 and args.gather != "none" and workload == args.workloads.split(",")[0]:
         res["allgather"] = gather_stretch(sim, batches, all_worlds, args, k, device, world)

@@ -982,8 +982,9 @@ int gd_attach_bev(gd_sim *s, float *bev) {
 }
 
 int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
-    if (!s || !out || which < 0 || which > 2) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
-    *out = which == 0 ? s->stat_graph_steps : which == 1 ? s->stat_plain_steps : s->stat_captures;
+    if (!s || !out || which < 0 || which > 5) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
+    *out = which == 0 ? s->stat_graph_steps : which == 1 ? s->stat_plain_steps : which == 2 ? s->stat_captures
+         : which == 3 ? s->d.set_fused_rows : which == 4 ? s->d.set_apw : s->d.live_count;
     return GD_OK;
 }
 

@@ -377,7 +377,8 @@ class SimManager:
 
     # ---- engine hooks used by bench.py / tests ----
     def stat(self, which):
-        """0 = steps replayed from the captured hipGraph, 1 = steps launched kernel by kernel, 2 = graph captures."""
+        """0 = steps replayed from the captured hipGraph, 1 = steps launched kernel by kernel, 2 = graph captures,
+        3 / 4 = the set-order road kernel's schedule for this batch (rows fused 0/1, agents per wave), 5 = live agents."""
         out = C.c_int64()
         _capi.check(self._L.gd_stat(self._h, int(which), C.byref(out)), "gd_stat")
         return out.value

@@ -212,7 +212,8 @@ int gd_set_stream(gd_sim *sim, void *stream);
  * caller keeps alive.  The rasters of the current state are computed at once; every later step / reset refreshes them. */
 int gd_attach_bev(gd_sim *sim, float *bev);
 /* Engine counters (tests and diagnostics).  which: 0 = steps replayed from the captured hipGraph,
- * 1 = steps launched kernel by kernel, 2 = hipGraph captures. */
+ * 1 = steps launched kernel by kernel, 2 = hipGraph captures; the schedule the engine chose for this batch (it never
+ * changes a result): 3 = set-order road kernel stores its rows itself (0 / 1), 4 = its agents per wave, 5 = live agents. */
 int gd_stat(gd_sim *sim, int32_t which, int64_t *out);
 
 /* Timing hooks for the bench: HIP events around the named kernel on the engine's stream.
