@@ -446,12 +446,41 @@ __device__ __forceinline__ void road_row(float *o, bool selected, bool knn, floa
     o[6] = (float)type; o[7] = q1.z; o[8] = (float)map_type;
 }
 
+// Launch order of the next k_map_obs (see "launch order" further down): counting sort of its workgroups by the cycles they
+// took, costliest first, by ONE workgroup of NT threads; `lds` needs 513 words.
+template <int NT>
+__device__ __forceinline__ void order_waves(const DevSim &d, int count, unsigned int *lds) {
+    unsigned int *s_cnt = lds, *s_off = lds + 256, *s_max = lds + 512;
+    const int tid = threadIdx.x;
+    for (int b = tid; b < 256; b += NT) s_cnt[b] = 0u;
+    if (tid == 0) *s_max = 0u;
+    __syncthreads();
+    unsigned int m = 0u;
+    for (int i = tid; i < count; i += NT) m = max(m, d.wave_cost[i]);
+    atomicMax(s_max, m);
+    __syncthreads();
+    const unsigned long long mx = max(*s_max, 1u);
+    auto bucket = [&](unsigned int c) -> int { return 255 - (int)min(255ull, (unsigned long long)c * 255ull / mx); };  // costliest first
+    for (int i = tid; i < count; i += NT) atomicAdd(&s_cnt[bucket(d.wave_cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int run = 0u;
+        for (int b = 0; b < 256; b++) { s_off[b] = run; run += s_cnt[b]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < count; i += NT) d.wave_order[atomicAdd(&s_off[bucket(d.wave_cost[i])], 1u)] = i;
+    __syncthreads();
+}
+
 template <int A_T>
 __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     constexpr int U = GD_ROWS_PER_THREAD;  // rows per thread (256 apart): independent load chains in flight
     constexpr int RB = 256 * U;   // rows per workgroup: consecutive, so their 36-byte rows are one contiguous 18 KB block
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     __shared__ __attribute__((aligned(16))) float s_rows[RB * 9];
+    static_assert(RB * 9 >= 513, "order_waves borrows the row buffer");
+    if (blockIdx.x == 0 && d.knn_order != GD_KNN_SET_ORDER)
+        order_waves<256>(d, d.W * (A_T / AW), reinterpret_cast<unsigned int *>(s_rows));
     const size_t rows = (size_t)d.W * A_T * K;
     const size_t base = (size_t)blockIdx.x * RB;
     // the agent's header (pose, count, first road: written by the selection kernel) and the slot's road index come in one
@@ -536,7 +565,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     const int lane = threadIdx.x;
     const int col = lane % AW, sub = lane / AW;
     const bool owner = sub == 0;
-    const int slot = d.wave_order[blockIdx.x];  // longest workgroups first (k_order_waves)
+    const int slot = d.wave_order[blockIdx.x];  // longest workgroups first (order_waves)
     const int w = slot / BPW;
     const int a0 = (slot % BPW) * AW;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
@@ -759,30 +788,9 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 // the number of heap inserts their agents need; in index order the launch ends when an unlucky slot finishes its second
 // long workgroup (measured: 18 % above the balanced time on the bench scene).  The agents move a fraction of a metre per
 // step, so a workgroup's cycles in this launch predict the next: the workgroups are re-sorted longest first (counting
-// sort over 256 cost buckets, one workgroup; the order inside a bucket is whatever the atomics give -- it only ever
-// changes WHEN a workgroup runs, never what it computes).
-__global__ __launch_bounds__(1024) void k_order_waves(DevSim d, int count) {
-    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged, nothing ran
-    __shared__ unsigned int s_max, s_cnt[256], s_off[256];
-    const int tid = threadIdx.x;
-    if (tid < 256) s_cnt[tid] = 0u;
-    if (tid == 0) s_max = 0u;
-    __syncthreads();
-    unsigned int m = 0u;
-    for (int i = tid; i < count; i += 1024) m = max(m, d.wave_cost[i]);
-    atomicMax(&s_max, m);
-    __syncthreads();
-    const unsigned long long mx = max(s_max, 1u);
-    auto bucket = [&](unsigned int c) -> int { return 255 - (int)min(255ull, (unsigned long long)c * 255ull / mx); };  // costliest first
-    for (int i = tid; i < count; i += 1024) atomicAdd(&s_cnt[bucket(d.wave_cost[i])], 1u);
-    __syncthreads();
-    if (tid == 0) {
-        unsigned int run = 0u;
-        for (int b = 0; b < 256; b++) { s_off[b] = run; run += s_cnt[b]; }
-    }
-    __syncthreads();
-    for (int i = tid; i < count; i += 1024) d.wave_order[atomicAdd(&s_off[bucket(d.wave_cost[i])], 1u)] = i;
-}
+// sort over 256 cost buckets; the order inside a bucket is whatever the atomics give -- it only ever changes WHEN a
+// workgroup runs, never what it computes).  The first workgroup of k_map_rows does it on its way in (order_waves above
+// that kernel): the row kernel runs right after the selection and nothing reads the order before the next step.
 
 // ---- set-order mode (gd_config.knn_order = GD_KNN_SET_ORDER) ----
 //
@@ -1215,7 +1223,6 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         const dim3 grid(d.W * (d.A / AW));
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64>), grid, dim3(64), 0, st, d);
         else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);
-        hipLaunchKernelGGL(k_order_waves, dim3(1), dim3(1024), 0, st, d, (int)grid.x);
     }
     const size_t rows = (size_t)d.W * d.A * K;
     const dim3 rgrid((unsigned int)((rows + 256 * GD_ROWS_PER_THREAD - 1) / (256 * GD_ROWS_PER_THREAD)));
