@@ -63,7 +63,7 @@ struct DevSim {
     // roads
     const int32_t *road_off;  // [W+1]
     int32_t *wave_order;   // [W * A / GD_MAP_OBS_AW] workgroups of the reference-order road kernel (world * A/AW + part) in launch order: longest first,
-                           // by road count at load time, then by the cycles each one took in the previous launch (order_waves, map_obs.hip)
+                           // by road count at load time, then by the cycles each one took in the previous launch (k_order_waves)
     uint32_t *wave_cost;   // [W * A / GD_MAP_OBS_AW] cycles of each of those workgroups in the last launch that ran them
     const float2 *road_xy;
     const float4 *road_aux;
