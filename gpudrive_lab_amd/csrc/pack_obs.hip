@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void k_pack_obs(DevSim d, float *out) {
             v.y = pack_element<A_T>(s_self, s_partner, s_road, 4 * q + 1);
             v.z = pack_element<A_T>(s_self, s_partner, s_road, 4 * q + 2);
             v.w = pack_element<A_T>(s_self, s_partner, s_road, 4 * q + 3);
-            reinterpret_cast<float4 *>(out + agent * D)[q] = v;
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 vv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(vv, reinterpret_cast<f4 *>(out + agent * D) + q);  // 782 MB written once: keep it out of the caches
         }
         __syncthreads();
     }
