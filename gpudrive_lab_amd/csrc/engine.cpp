@@ -462,7 +462,7 @@ struct gd_sim {
                 }
                 HIP_CHECK(hipMemcpy(d_road_rec, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
             }
-            HIP_CHECK(hipMemset(d.sel_hdr, 0xff, sizeof(float4) * 2 * static_cast<size_t>(W) * d.A));  // count -1: nothing selected yet
+            HIP_CHECK(hipMemsetAsync(d.sel_hdr, 0xff, sizeof(float4) * 2 * static_cast<size_t>(W) * d.A, stream));  // count -1: nothing selected yet (ordered before the kernels of this stream)
             if (nbox) HIP_CHECK(hipMemcpy(d_boxes, boxes.data(), nbox * sizeof(gd::RoadBox), hipMemcpyHostToDevice));
         }
         {
@@ -524,7 +524,7 @@ struct gd_sim {
             for (int k = 0; k < W; k++)
                 for (int q = 0; q < parts; q++) waves[static_cast<size_t>(k) * parts + q] = order[k] * parts + q;
             HIP_CHECK(hipMemcpy(d.wave_order, waves.data(), sizeof(int32_t) * waves.size(), hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemset(d.wave_cost, 0, sizeof(uint32_t) * waves.size()));
+            HIP_CHECK(hipMemsetAsync(d.wave_cost, 0, sizeof(uint32_t) * waves.size(), stream));
         }
         HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.box_off), box_off.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
         d.road_xy = static_cast<const float2 *>(d_road_xy);
