@@ -340,3 +340,48 @@ def test_set_order_bounds_survive_resets_and_map_changes(oracle_mod):
     P.compare_roadmap_as_set(gpu, orc)
     advance(3)
     gpu.close()
+
+
+def test_live_agent_lists_follow_delete_agents_and_set_maps(oracle_mod, monkeypatch):
+    """BEV launches one workgroup per LIVE agent and the set-order road kernel one per live group of agent slots: both
+    lists are rebuilt with the worlds.  After deleteAgents and set_maps (other agent counts per world) the rasters, the
+    LiDAR rows and the road rows must still be the oracle's."""
+    kw = dict(CLASSIC, enableLidar=1)
+    scenes = [SCENE_407, TEST_JSON, SCENE_4]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, knn_order=1, enable_bev=True, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, enableBev=1, **kw)
+    rng = np.random.default_rng(23)
+
+    def check(steps):
+        for _ in range(steps):
+            act = P.random_actions(rng, orc.W, orc.A, 0)
+            RC.write_actions(gpu, act)
+            np.copyto(orc.action_tensor(), act)
+            gpu.step()
+            orc.step()
+            gpu.debug_set_state(orc.get_state())
+            gpu.reset([])
+            orc.reset([])
+            P.compare_roadmap_as_set(gpu, orc)
+            P.compare_bev(gpu, orc)
+            P.compare_lidar(gpu, orc)
+            P.compare_ints(gpu, orc, ["shape_tensor", "done_tensor", "info_tensor"])
+    check(2)
+    ids = np.asarray(orc.agent_id_tensor())
+    n0 = int(np.asarray(orc.shape_tensor())[0, 0])
+    victims = {0: [int(ids[0, k]) for k in range(0, n0, 2)], 2: [int(ids[2, 1])]}   # half of world 0 goes
+    gpu.deleteAgents(victims)
+    orc.deleteAgents(victims)
+    assert int(np.asarray(orc.shape_tensor())[0, 0]) < n0
+    gpu.debug_set_state(orc.get_state())
+    gpu.reset([])
+    orc.reset([])
+    check(2)
+    new = [TEST_JSON, SCENE_4, SCENE_407]
+    gpu.set_maps(new)
+    orc.set_maps(new)
+    gpu.debug_set_state(orc.get_state())
+    gpu.reset([])
+    orc.reset([])
+    check(2)
+    gpu.close()
