@@ -13,10 +13,15 @@ Workload (BASELINE.json configs[1]): 1024 worlds x 64 agents per GPU, classic bi
 synthetic exact-64 scenes of SURVEY.md section 8d (64 live agents, 4096 road segments per world).
 Secondary (reported under "other_workloads"): the committed Waymo scenes tiled round-robin.
 
-Kernel times in the line (`kernels`, `roofline.avg_kernel_us`) are HIP-event times of the SAME steps the wall clock
-brackets (events on the engine's stream around every launch), so a kernel average can be compared with `ms_per_step`
-directly.  With N > 1 ranks a second stretch measures BASELINE configs[3]'s observation all-gather (RCCL), overlapped
-with the following step (`allgather` in the line; `--gather none` skips it).
+Two stretches of K steps per workload, back to back on the same simulator:
+  1. the TIMED REGION (`ms_per_step`, `value`): `step()` exactly as a user calls it -- the step's kernels replayed from
+     the captured hipGraph, no instrumentation;
+  2. the same K steps again with HIP events on the engine's stream around every launch (`gd_kernel_timing_*`: the
+     kernels are then launched one by one): `kernels`, `roofline.avg_kernel_us`, and that stretch's own wall clock
+     `ms_per_step_events`, which the kernel averages add up to.
+With N > 1 ranks a further stretch measures BASELINE configs[3]'s observation all-gather (RCCL), overlapped
+with the following step (`allgather` in the line; `--gather none` skips it).  `--headless` adds the two FPS lines of the
+reference's own benchmark CLI (src/headless.cpp:145-155) on stderr.
 """
 import argparse
 import hashlib
@@ -49,7 +54,7 @@ def source_stamp():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gpudrive_lab_amd", "csrc")
     for name in sorted(os.listdir(d)) + ["../../include/gpudrive_amd.h"]:
-        if name.endswith((".hip", ".cpp", ".hpp", ".h")):
+        if name.endswith((".hip", ".cpp", ".hpp", ".h")) or name == "Makefile":
             with open(os.path.join(d, name), "rb") as fh:
                 h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
@@ -57,6 +62,11 @@ def source_stamp():
 
 WAYMO = [os.path.join(ROOT, "tests", "data", n) for n in
          ("test.json", "tfrecord-00002-of-01000_407.json", "tfrecord-00000-of-01000_4.json")]
+
+
+def split_workload(name):
+    """'synthetic_set' -> ('synthetic', 1): the same scenes with gd_config.knn_order = GD_KNN_SET_ORDER."""
+    return (name[:-4], 1) if name.endswith("_set") else (name, 0)
 
 
 def params_for(workload):
@@ -125,13 +135,15 @@ def bench_workload(workload, args, rank, local_rank, world, device):
         return _bench_workload(workload, args, rank, local_rank, world, device)
 
 
-def _bench_workload(workload, args, rank, local_rank, world, device):
+def _bench_workload(name, args, rank, local_rank, world, device):
+    workload, knn_order = split_workload(name)
+    knn_order = max(knn_order, args.knn_order)
     kw = params_for(workload)
     if workload == "cfg3":
         args = argparse.Namespace(**dict(vars(args), worlds=4 * args.worlds))
     scenes = scenes_for(workload, args.worlds, rank)
     t0 = time.time()
-    sim = make_sim(scenes, kw, args.agents, local_rank, knn_order=args.knn_order,
+    sim = make_sim(scenes, kw, args.agents, local_rank, knn_order=knn_order,
                    lidar_half_angle=float(np.pi) if workload == "lidar" else 0.0,  # 360 degrees
                    enable_bev=workload == "bev")  # the reference rasterises the 200 x 200 BEV on every step
     torch.cuda.synchronize(device)
@@ -146,24 +158,40 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
         from gpudrive_lab_amd.episode import EpisodeTracker
         tracker = EpisodeTracker(sim)
 
+    def timed_stretch(k):
+        sharding.barrier(device)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        k = run_steps(sim, batches, all_worlds, args.steps, start=k, tracker=tracker)
+        torch.cuda.synchronize(device)
+        sharding.barrier(device)
+        return k, time.perf_counter() - t0
+
     k = run_steps(sim, batches, all_worlds, args.warmup, tracker=tracker)
-    # HIP events around every kernel launch of the timed steps themselves (gd_kernel_timing_*): the per-kernel averages
-    # in the line describe the same steps as ms_per_step
+    # ---- 1. the timed region: step() as a user calls it (hipGraph replay, no instrumentation) ----
+    graph0, plain0 = sim.stat(0), sim.stat(1)
+    k, local_elapsed = timed_stretch(k)
+    graph_steps, plain_steps = sim.stat(0) - graph0, sim.stat(1) - plain0
+    elapsed = sharding.reduce_max(local_elapsed, device)
+    elapsed_min = -sharding.reduce_max(-local_elapsed, device)
+    # ---- 2. the same K steps again with HIP events around every kernel launch (kernel by kernel); a few untimed steps
+    # first so that nothing of the switch (event creation, first plain launches) lands in the stretch ----
     sim.kernel_timing(True)
-    sharding.barrier(device)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    k = run_steps(sim, batches, all_worlds, args.steps, start=k, tracker=tracker)
-    torch.cuda.synchronize(device)
-    sharding.barrier(device)
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.reduce_max(elapsed, device)
+    k = run_steps(sim, batches, all_worlds, 3, start=k, tracker=tracker)
+    sim.kernel_timing(True)  # zeroes the sums
+    k, ev_elapsed = timed_stretch(k)
+    ev_elapsed = sharding.reduce_max(ev_elapsed, device)
     total_live = sharding.reduce_sum(live, device)
     res = dict(
-        workload=workload, seconds=elapsed, ms_per_step=1e3 * elapsed / args.steps,
+        workload=name, seconds=elapsed, ms_per_step=1e3 * elapsed / args.steps,
+        ms_per_step_events=1e3 * ev_elapsed / args.steps,
+        ms_per_step_min_rank=1e3 * elapsed_min / args.steps,
+        knn_order=knn_order,
         live_agents_per_rank=live, road_entities_per_rank=roads, init_seconds=init_s,
         agent_steps_per_s=total_live * args.steps / elapsed,
         padded_agent_steps_per_s=world * args.worlds * args.agents * args.steps / elapsed,
+        timed_region=dict(graph_steps=graph_steps, plain_steps=plain_steps),
+        worlds=args.worlds,
     )
     names = {0: "k_world_step", 1: "k_map_obs+k_map_rows"}
     if workload == "lidar":
@@ -187,10 +215,10 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
     traffic = None
     try:
         if workload in ("synthetic", "waymo"):
-            tkey = ("set_" if args.knn_order == 1 else "exact_") + workload
+            tkey = ("set_" if knn_order == 1 else "exact_") + workload
         else:  # lidar, bev, rl_loop: collected in the default (reference) row order only
-            tkey = workload if args.knn_order == 0 else ("set_cfg3" if workload == "cfg3" else None)
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+            tkey = workload if knn_order == 0 else ("set_cfg3" if workload == "cfg3" else None)
+        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
             tj = json.load(fh)
         if tj.get("source_stamp") == source_stamp() and args.worlds == (4096 if workload == "cfg3" else 1024) and args.agents == 64:
             traffic = tj.get(tkey, {}).get("hbm_bytes_per_launch")
@@ -214,12 +242,14 @@ def _bench_workload(workload, args, rank, local_rank, world, device):
         extra["k_world_step"] = dict(algorithmic_bytes_per_launch=b, achieved=b / (kt["k_world_step"]["avg_us"] * 1e-6) / 1e9,
                                      frac=b / (kt["k_world_step"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, unit="GB/s")
     res["other_rooflines"] = extra
+    res["kernels_sum_us"] = sum(v["avg_us"] for v in kt.values())
     res["engine"] = dict(graph_steps=sim.stat(0), plain_steps=sim.stat(1), graph_captures=sim.stat(2),
                          set_order_rows_fused=sim.stat(3), set_order_agents_per_wave=sim.stat(4),
+                         road_kernel_agents_per_wave=sim.stat(6),
                          schedule_env={k: os.environ[k] for k in ("GPUDRIVE_NO_GRAPH", "GPUDRIVE_SET_FUSED_ROWS",
                                                                    "GPUDRIVE_SET_AGENTS_PER_WAVE") if k in os.environ})
     # ---- BASELINE configs[3]: observation all-gather over RCCL, overlapped with the next step ----
-    if world > 1 and args.gather != "none" and workload == args.workloads.split(",")[0]:
+    if world > 1 and args.gather != "none" and name == args.workloads.split(",")[0]:
         res["allgather"] = gather_stretch(sim, batches, all_worlds, args, k, device, world)
     sim.close()
     return res
@@ -230,7 +260,7 @@ def gather_stretch(sim, batches, all_worlds, args, k, device, world):
     agents' rows (compact) on a side stream while the next step runs (sharding.ObservationGather)."""
     import torch.distributed as dist
     D = 6 + (args.agents - 1) * 6 + 200 * 13
-    og = sharding.ObservationGather(args.gather, args.worlds * args.agents, D, device)
+    og = sharding.ObservationGather(args.gather, args.worlds * args.agents, D, device, timing=True)
     og.set_mask(sim.controlled_state_tensor().to_torch()[..., 0] == 1)
     act = sim.action_tensor().to_torch()
     steps = args.gather_steps
@@ -305,16 +335,23 @@ def cpu_baseline(args, budget_s=15.0):
         dt = time.perf_counter() - t0
         sim.close()
         return live * steps / dt, worlds, steps, dt
-    # one world per thread (Madrona's ThreadPoolExecutor runs one world per task, src/mgr.cpp:527-535), at most 64
-    # threads: beyond that the 4096-road scan of the port is memory-bound on the host and scales no further
+    # one world per thread (Madrona's ThreadPoolExecutor runs one world per task, src/mgr.cpp:527-535).  The headline CPU
+    # figure uses at most 64 threads; the same with EVERY host core is measured beside it (`all_cores_value`): the
+    # port's 4096-road scan per agent is memory-bound on the host well before 256 threads.
     threads = max(1, min(cores, 64))
-    rate, worlds, steps, dt = run(threads, threads, budget_s * 0.7)
-    rate1, _, steps1, dt1 = run(1, 1, budget_s * 0.3)
+    rate, worlds, steps, dt = run(threads, threads, budget_s * 0.5)
+    rate_all, steps_all, dt_all = None, 0, 0.0
+    if cores > threads:
+        rate_all, _, steps_all, dt_all = run(cores, cores, budget_s * 0.3)
+    rate1, _, steps1, dt1 = run(1, 1, budget_s * 0.2)
     return dict(value=rate, unit="agent-steps/s", cores=threads, host_cores=cores, kind="port",
-                single_thread_value=rate1,
+                single_thread_value=rate1, all_cores_value=rate_all,
                 sample="%d synthetic exact-64 worlds (R_w=4096) x %d steps on %d OpenMP threads (one world per thread), %.1f s; "
-                       "1 world x %d steps on 1 thread, %.1f s; the reference's own CPU ExecMode cannot be built "
-                       "(Madrona submodule absent)" % (worlds, steps, threads, dt, steps1, dt1))
+                       "%s1 world x %d steps on 1 thread, %.1f s; the reference's own CPU ExecMode cannot be built "
+                       "(Madrona submodule absent)"
+                       % (worlds, steps, threads, dt,
+                          ("%d worlds x %d steps on all %d host cores, %.1f s; " % (cores, steps_all, cores, dt_all)) if rate_all else "",
+                          steps1, dt1))
 
 
 def main():
@@ -329,8 +366,11 @@ def main():
                     help="N > 1 only: after the timed region, a stretch with the observation all-gather of BASELINE configs[3] "
                          "(raw = every agent slot's packed observation, compact = controlled agents only), overlapped with the next step")
     ap.add_argument("--gather-steps", type=int, default=30)
-    ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop",
-                    help="first = primary; synthetic | waymo | lidar (Waymo tiles + 360-degree LiDAR)")
+    ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop,synthetic_set,waymo_set,cfg3_set",
+                    help="first = primary; synthetic | waymo | cfg3 | lidar (Waymo tiles + 360-degree LiDAR) | bev | rl_loop; "
+                         "a _set suffix = the same scenes in set order (knn_order 1)")
+    ap.add_argument("--headless", action="store_true",
+                    help="also print the reference CLI's two lines (src/headless.cpp:145-155) for the primary workload on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default=None, choices=(None, "nccl", "gloo"),
                     help="default: nccl (RCCL); gloo + --single-device rehearses the N>1 path on one GPU")
@@ -354,7 +394,13 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
+    dist_info = None
+    if torch.distributed.is_initialized():
+        import torch.distributed as dist
+        dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
+                         ms_per_step_max_rank=primary["ms_per_step"], ms_per_step_min_rank=primary["ms_per_step_min_rank"])
     if rank == 0:
+        order_txt = {0: "reference heap order", 1: "SET order: same rows, road-index order"}[primary["knn_order"]]
         line = {
             "metric": "agent-steps/sec at 1024 worlds x 64 agents; achieved HBM GB/s on obs kernel",
             "value": primary["agent_steps_per_s"],
@@ -372,26 +418,39 @@ def main():
                 "workload": "%d worlds x %d agents per GPU, classic bicycle dynamics, %d-partner + 200-road-point "
                             "k-NN obs (%s), radius 50, collisions ignored, reset every 91 steps; "
                             "scenes: seeded synthetic exact-64 (64 live agents, 4096 road-edge segments per world)"
-                            % (args.worlds, args.agents, args.agents - 1,
-                               "reference heap order" if args.knn_order == 0 else "SET order: same rows, road-index order"),
+                            % (args.worlds, args.agents, args.agents - 1, order_txt),
                 "worlds_per_gpu": args.worlds, "max_agents": args.agents,
                 "parallelism": "worlds sharded %d-way, no per-step collective" % world,
             },
             "padded_agent_steps_per_s": primary["padded_agent_steps_per_s"],
+            "timed_region": "step() as a user calls it: the step's kernels replayed from the captured hipGraph (%d graph / %d plain "
+                            "steps), no instrumentation" % (primary["timed_region"]["graph_steps"], primary["timed_region"]["plain_steps"]),
+            "ms_per_step_events": primary["ms_per_step_events"],
+            "kernels_sum_us": primary["kernels_sum_us"],
             "roofline": primary["roofline"],
             "kernels": primary["kernels"],
-            "kernel_times": "HIP events around every launch of the timed steps themselves (same steps as ms_per_step)",
+            "kernel_times": "HIP events around every launch of a second stretch of the same K steps right after the timed region "
+                            "(kernels launched one by one; its wall clock is ms_per_step_events)",
             "other_rooflines": primary.get("other_rooflines"),
-            "engine": dict(primary.get("engine", {}), source_stamp=source_stamp(), road_kernel_agents_per_wave=32),
+            "engine": dict(primary.get("engine", {}), source_stamp=source_stamp()),
+            "distributed": dist_info,
             "allgather": primary.get("allgather"),
             "cpu_baseline": cpu,
             "other_workloads": [
-                {k: r[k] for k in ("workload", "agent_steps_per_s", "padded_agent_steps_per_s", "ms_per_step",
-                                   "live_agents_per_rank", "road_entities_per_rank", "roofline", "kernels", "other_rooflines")}
+                {k: r[k] for k in ("workload", "knn_order", "worlds", "agent_steps_per_s", "padded_agent_steps_per_s", "ms_per_step",
+                                   "ms_per_step_events", "kernels_sum_us", "live_agents_per_rank", "road_entities_per_rank",
+                                   "roofline", "kernels", "other_rooflines")}
                 for r in results[1:]],
             "init_seconds": primary["init_seconds"],
         }
         print(json.dumps(line), flush=True)
+        if args.headless:
+            # the reference CLI's two lines (src/headless.cpp:145-155): FPS = steps * worlds / s, and its "Agent-Normalized
+            # FPS" = FPS * total live agents (as printed there -- not divided by the worlds); then what it presumably means
+            fps = args.steps * args.worlds * world / primary["seconds"]
+            tot = primary["live_agents_per_rank"] * world
+            sys.stderr.write("FPS %f\nAgent-Normalized FPS %f\n" % (fps, fps * tot))
+            sys.stderr.write("(live agent-steps per second: %f)\n" % primary["agent_steps_per_s"])
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

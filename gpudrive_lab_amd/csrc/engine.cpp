@@ -117,9 +117,15 @@ struct gd_sim {
     hipEvent_t flag_ev[kRing] = {};
     int ring_pos = 0;
     // kernel timing
+    // A fixed ring of event pairs per kernel, created when timing is switched on: a launch re-records the oldest pair
+    // after its elapsed time has been read.  (Round 2 kept one pair per launch alive until the read-out; the runtime's
+    // signal pool then ran dry in the middle of a timed stretch and one hipLaunchKernel blocked the host for 14 ms --
+    // tools/trace_gap.sh -- so that a 20-step wall clock was far above the sum of its kernels.)
+    static constexpr size_t kEvRing = 32;
     bool timing = false;
     std::vector<EventPair> ev_pool[gd::KERNEL_TIMED];
-    size_t ev_used[gd::KERNEL_TIMED] = {};
+    size_t ev_head[gd::KERNEL_TIMED] = {};  // oldest recorded pair
+    size_t ev_used[gd::KERNEL_TIMED] = {};  // recorded pairs not read yet
     double ev_ms[gd::KERNEL_TIMED] = {};
     int64_t ev_launches[gd::KERNEL_TIMED] = {};
 
@@ -156,32 +162,27 @@ struct gd_sim {
         return static_cast<T *>(p);
     }
 
-    void collect_timing(int k) {
-        for (size_t i = 0; i < ev_used[k]; i++) {
+    void collect_timing(int k, size_t keep = 0) {  // read the oldest pairs until `keep` are left
+        while (ev_used[k] > keep) {
+            const EventPair &e = ev_pool[k][ev_head[k]];
             float ms = 0.f;
-            if (hipEventSynchronize(ev_pool[k][i].stop) == hipSuccess &&
-                hipEventElapsedTime(&ms, ev_pool[k][i].start, ev_pool[k][i].stop) == hipSuccess) {
+            if (hipEventSynchronize(e.stop) == hipSuccess && hipEventElapsedTime(&ms, e.start, e.stop) == hipSuccess) {
                 ev_ms[k] += ms;
                 ev_launches[k]++;
             }
+            ev_head[k] = (ev_head[k] + 1) % ev_pool[k].size();
+            ev_used[k]--;
         }
-        ev_used[k] = 0;
     }
 
     void launch(int which, bool move) {
         const bool timed = timing && which < gd::KERNEL_TIMED && !d.gate_any;  // gated reset passes are mostly empty launches
         EventPair ep{};
         if (timed) {
-            if (ev_used[which] == ev_pool[which].size()) {
-                if (ev_pool[which].size() >= 4096) collect_timing(which);
-                if (ev_used[which] == ev_pool[which].size()) {
-                    EventPair n{};
-                    HIP_CHECK(hipEventCreate(&n.start));
-                    HIP_CHECK(hipEventCreate(&n.stop));
-                    ev_pool[which].push_back(n);
-                }
-            }
-            ep = ev_pool[which][ev_used[which]++];
+            // ring full: read the older half (those launches finished long ago; the host stays well ahead of the GPU)
+            if (ev_used[which] == ev_pool[which].size()) collect_timing(which, ev_pool[which].size() / 2);
+            ep = ev_pool[which][(ev_head[which] + ev_used[which]) % ev_pool[which].size()];
+            ev_used[which]++;
             HIP_CHECK(hipEventRecord(ep.start, stream));
         }
         if (which == gd::KERNEL_BEV) gd::launch_bev(d, stream);
@@ -372,6 +373,13 @@ struct gd_sim {
                 auto sit = scene_cache.find(path);  // filled above
                 hw = std::make_shared<gd::HostWorld>();
                 gd::build_host_world(*sit->second, params, A, del, ndel, *hw);
+                // the row kernel's 32-byte road record restores the z scale from the entity type (1 for stop signs, 0.1
+                // for everything else: scene.cpp put_road callers); checked here, before anything of this call is uploaded
+                for (size_t r = 0; r * 8 < hw->road_aux.size(); r++) {
+                    const float *a = &hw->road_aux[r * 8];
+                    if (a[4] != (static_cast<int>(a[5]) == gd::ET_StopSign ? 1.f : 0.1f))
+                        throw std::runtime_error("road record: unexpected z scale for this entity type");
+                }
                 world_cache.emplace(key, hw);
             }
             st.traj.insert(st.traj.end(), hw->trajectory.begin(), hw->trajectory.end());
@@ -421,14 +429,20 @@ struct gd_sim {
             box_off[w + 1] = box_off[w] + static_cast<int32_t>(w_boxes[w].size());
         }
         const size_t nroad = road_off[W], nbox = box_off[W];
-        if (nroad > road_cap) {
+        // k_map_obs requests chunks of 32 roads up to 256 roads past a world's last one, and the fused set-order write-out
+        // reads road_rec[first road of the world] even for a world without roads: the arrays always end in 320 readable
+        // pad entries (also when a rebuild fits the old capacity, and when no world has a road)
+        if (nroad + 320 > road_cap || !d_road_xy) {
             if (d_road_xy) (void)hipFree(d_road_xy);
             if (d_road_aux) (void)hipFree(d_road_aux);
             if (d_road_rec) (void)hipFree(d_road_rec);
-            road_cap = nroad + nroad / 8 + 320;  // k_map_obs requests chunks of 32 roads up to 256 roads past a world's last one
+            road_cap = nroad + nroad / 8 + 640;
             HIP_CHECK(hipMalloc(&d_road_xy, road_cap * sizeof(float) * 2));
             HIP_CHECK(hipMalloc(&d_road_aux, road_cap * sizeof(float) * 8));
             HIP_CHECK(hipMalloc(&d_road_rec, road_cap * sizeof(float) * 8));
+            HIP_CHECK(hipMemset(d_road_xy, 0, road_cap * sizeof(float) * 2));
+            HIP_CHECK(hipMemset(d_road_aux, 0, road_cap * sizeof(float) * 8));
+            HIP_CHECK(hipMemset(d_road_rec, 0, road_cap * sizeof(float) * 8));
         }
         if (nbox > box_cap) {
             if (d_boxes) (void)hipFree(d_boxes);
@@ -446,13 +460,11 @@ struct gd_sim {
             if (nroad) {
                 HIP_CHECK(hipMemcpy(d_road_xy, xy.data(), xy.size() * sizeof(float), hipMemcpyHostToDevice));
                 HIP_CHECK(hipMemcpy(d_road_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice));
-                // the row kernel's 32-byte record: aux is (qw, qz, d0, d1, d2, type, id, mapType); d2 is 1 for stop signs and
-                // 0.1 for everything else (scene.cpp put_road callers), which the kernel restores from the type
+                // the row kernel's 32-byte record: aux is (qw, qz, d0, d1, d2, type, id, mapType); d2 is a function of the
+                // type (validated while staging), which the kernel restores
                 std::vector<float> rec(nroad * 8);
                 for (size_t r = 0; r < nroad; r++) {
                     const float *a = &aux[r * 8];
-                    if (a[4] != (static_cast<int>(a[5]) == gd::ET_StopSign ? 1.f : 0.1f))
-                        throw std::runtime_error("road record: unexpected z scale for this entity type");
                     const uint32_t bits = (static_cast<uint32_t>(static_cast<int>(a[5])) & 0xffu) |
                                           (static_cast<uint32_t>(static_cast<int>(a[7]) + 1) << 8);
                     float fb;
@@ -982,9 +994,9 @@ int gd_attach_bev(gd_sim *s, float *bev) {
 }
 
 int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
-    if (!s || !out || which < 0 || which > 5) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
+    if (!s || !out || which < 0 || which > 6) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
     *out = which == 0 ? s->stat_graph_steps : which == 1 ? s->stat_plain_steps : which == 2 ? s->stat_captures
-         : which == 3 ? s->d.set_fused_rows : which == 4 ? s->d.set_apw : s->d.live_count;
+         : which == 3 ? s->d.set_fused_rows : which == 4 ? s->d.set_apw : which == 5 ? s->d.live_count : GD_MAP_OBS_AW;
     return GD_OK;
 }
 
@@ -996,6 +1008,12 @@ int gd_kernel_timing_enable(gd_sim *s, int32_t enable) {
             s->collect_timing(k);
             s->ev_ms[k] = 0;
             s->ev_launches[k] = 0;
+            while (enable && s->ev_pool[k].size() < gd_sim::kEvRing) {  // every event exists before the first timed launch
+                EventPair n{};
+                HIP_CHECK(hipEventCreate(&n.start));
+                HIP_CHECK(hipEventCreate(&n.stop));
+                s->ev_pool[k].push_back(n);
+            }
         }
         s->timing = enable != 0;
     });

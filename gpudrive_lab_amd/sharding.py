@@ -7,6 +7,7 @@ the backend is "nccl"; gloo in the CPU tests).  Every peer's shard travels over 
 link in an all-gather of equal blocks, so the time is about shard_bytes / 153 GB/s, not a ring's
 7 * shard_bytes / 153 GB/s.
 """
+import collections
 import os
 
 import torch
@@ -90,9 +91,12 @@ class ObservationGather:
     `start(block)` copies / compacts `block` into a send buffer on the caller's stream and launches the all-gather on
     a side stream; `wait()` makes the caller's stream wait for it and returns (gathered [world * cap, D], counts
     [world]) -- rows beyond counts[r] in rank r's section are stale padding.  Two send / receive buffers alternate, so
-    the gather of step k overlaps step k + 1.  On CPU tensors (gloo, tests) everything runs inline."""
+    the gather of step k overlaps step k + 1; `start` itself makes the caller's stream wait for the gather that last
+    used the buffer pair it is about to overwrite (two starts back), whether or not the caller waited for it.  The
+    receive buffer `wait()` returned stays valid until the second `start` after it.  `timing=True` keeps the (start,
+    stop) events of the last `timing_window` gathers for `mean_ms()`.  On CPU tensors (gloo, tests) everything runs inline."""
 
-    def __init__(self, mode, world_agents, feature_dim, device, dtype=torch.float32):
+    def __init__(self, mode, world_agents, feature_dim, device, dtype=torch.float32, timing=False, timing_window=256):
         assert mode in ("raw", "compact")
         self.mode, self.device, self.dim = mode, torch.device(device), int(feature_dim)
         self.rows = int(world_agents)
@@ -106,7 +110,9 @@ class ObservationGather:
         self._dtype = dtype
         self._alloc()
         self._k, self._pending = 0, None
-        self.events = []  # (start, stop) cuda events of every launched gather, for timing
+        self._done = [None, None]  # completion event of the last gather that used buffer pair k
+        self.timing = bool(timing)
+        self.events = collections.deque(maxlen=int(timing_window))  # (start, stop) cuda events, only with timing=True
 
     def _alloc(self):
         mk = lambda n: torch.empty((n, self.dim), dtype=self._dtype, device=self.device)
@@ -128,6 +134,10 @@ class ObservationGather:
         else:
             self.counts = c.cpu()
         self.cap = max(int(self.counts.max().item()), 1)
+        # a gather of the previous start() may still be running on the side stream with the old buffers
+        if self.stream is not None:
+            self.stream.synchronize()
+        self._pending, self._done = None, [None, None]
         self._alloc()
 
     @property
@@ -137,6 +147,8 @@ class ObservationGather:
     def start(self, block):
         k = self._k
         self._k ^= 1
+        if self._done[k] is not None:  # the gather two starts back may still be reading send[k] / writing recv[k]
+            torch.cuda.current_stream(self.device).wait_event(self._done[k])
         src = block.reshape(-1, self.dim)
         if self.mode == "compact":
             torch.index_select(src, 0, self.index, out=self.send[k][:self.count])
@@ -151,8 +163,9 @@ class ObservationGather:
             ready.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record(self.stream)
+                ev0, ev1 = torch.cuda.Event(enable_timing=self.timing), torch.cuda.Event(enable_timing=self.timing)
+                if self.timing:
+                    ev0.record(self.stream)
                 if self.nccl:
                     dist.all_gather_into_tensor(self.recv[k], self.send[k])
                 else:  # gloo rehearsal on one GPU: through host memory
@@ -160,8 +173,10 @@ class ObservationGather:
                     dist.all_gather_into_tensor(host, self.send[k].cpu())
                     self.recv[k].copy_(host)
                 ev1.record(self.stream)
-                self.events.append((ev0, ev1))
+                if self.timing:
+                    self.events.append((ev0, ev1))
             self._pending = (k, ev1)
+            self._done[k] = ev1
         else:
             dist.all_gather_into_tensor(self.recv[k], self.send[k])
             self._pending = (k, None)

@@ -213,11 +213,13 @@ int gd_set_stream(gd_sim *sim, void *stream);
 int gd_attach_bev(gd_sim *sim, float *bev);
 /* Engine counters (tests and diagnostics).  which: 0 = steps replayed from the captured hipGraph,
  * 1 = steps launched kernel by kernel, 2 = hipGraph captures; the schedule the engine chose for this batch (it never
- * changes a result): 3 = set-order road kernel stores its rows itself (0 / 1), 4 = its agents per wave, 5 = live agents. */
+ * changes a result): 3 = set-order road kernel stores its rows itself (0 / 1), 4 = its agents per wave, 5 = live agents,
+ * 6 = agents per wave of the reference-order road kernel (compile-time GD_MAP_OBS_AW of this build). */
 int gd_stat(gd_sim *sim, int32_t which, int64_t *out);
 
-/* Timing hooks for the bench: HIP events around the named kernel on the engine's stream.
- * kernel: 0 = state step, 1 = road observation, 2 = LiDAR, 3 = BEV. */
+/* Timing hooks for the bench: HIP events around the named kernel on the engine's stream (a fixed ring of event pairs,
+ * created by the enable call; steps run kernel by kernel, not from the hipGraph, while it is on).  Enabling again
+ * while enabled zeroes the sums.  kernel: 0 = state step, 1 = road observation, 2 = LiDAR, 3 = BEV. */
 int gd_kernel_timing_enable(gd_sim *sim, int32_t enable);
 int gd_kernel_timing_read(gd_sim *sim, int32_t kernel, double *total_ms, int64_t *launches);
 

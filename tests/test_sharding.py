@@ -6,6 +6,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 from gpudrive_lab_amd import sharding
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,22 +36,25 @@ _WORKER = textwrap.dedent("""
     sys.path.insert(0, %r)
     import torch
     from gpudrive_lab_amd import sharding
-    rank, local_rank, world = sharding.init_process_group(backend="gloo")
-    assert world == 2 and torch.distributed.is_initialized()
-    dev = torch.device("cpu")
+    backend = os.environ.get("GD_TEST_BACKEND", "gloo")
+    rank, local_rank, world = sharding.init_process_group(backend=backend)
+    assert world == 2 and torch.distributed.is_initialized() and torch.distributed.get_backend() == backend
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
     # each rank owns 3 worlds; obs block [W_local, A, F] filled with its global world index
     lo, hi = sharding.shard_range(6, rank, world)
     assert (lo, hi) == ((0, 3) if rank == 0 else (3, 6))
-    local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 4, 5).contiguous()
+    local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(-1, 4, 5).contiguous().to(dev)
     sharding.barrier(dev)
     full = sharding.gather_observations(local)
     assert full.shape == (6, 4, 5)
-    assert torch.equal(full[:, 0, 0], torch.arange(6, dtype=torch.float32))
+    assert torch.equal(full[:, 0, 0].cpu(), torch.arange(6, dtype=torch.float32))
     # bench aggregation: MAX of the elapsed time, SUM of the live agents
     assert sharding.reduce_max(1.0 + rank, dev) == 2.0
     assert sharding.reduce_sum(10 + rank, dev) == 21.0
     # preallocated output buffer is reused
-    out = torch.empty(6, 4, 5)
+    out = torch.empty(6, 4, 5, device=dev)
     assert sharding.gather_observations(local, out).data_ptr() == out.data_ptr()
     # config 4: the packed observation [W_local, A, D] of the real shape (A = 64: D = 6 + 63 * 6 + 200 * 13), raw and
     # controlled-agent-compacted, double-buffered; rank r's rows must land in section r, in agent order
@@ -61,29 +66,50 @@ _WORKER = textwrap.dedent("""
     peer_obs = torch.rand(W, A, D, generator=peer)
     peer_ctrl = torch.rand(W, A, generator=peer) < (0.3 if rank == 1 else 0.6)
     both = {rank: (obs, ctrl), 1 - rank: (peer_obs, peer_ctrl)}
+    obs_d, ctrl_d = obs.to(dev), ctrl.to(dev)
     raw = sharding.ObservationGather("raw", W * A, D, dev)
-    raw.start(obs)
+    raw.start(obs_d)
     full, counts = raw.wait()
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
     assert full.shape == (2 * W * A, D) and counts.tolist() == [W * A, W * A] and raw.bytes_per_rank == W * A * D * 4
     for r in range(2):
-        assert torch.equal(full[r * W * A:(r + 1) * W * A], both[r][0].reshape(-1, D))
-    cg = sharding.ObservationGather("compact", W * A, D, dev)
-    cg.set_mask(ctrl)
+        assert torch.equal(full[r * W * A:(r + 1) * W * A].cpu(), both[r][0].reshape(-1, D))
+    cg = sharding.ObservationGather("compact", W * A, D, dev, timing=True, timing_window=4)
+    cg.set_mask(ctrl_d)
     n = [int(both[r][1].sum()) for r in range(2)]
     assert cg.counts.tolist() == n and cg.cap == max(n)
-    for step in range(3):   # the two buffers alternate
-        cg.start(obs + step)
-        full, counts = cg.wait()
+
+    def check(full, offset):
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
         assert full.shape == (2 * cg.cap, D)
         for r in range(2):
-            exp = (both[r][0] + step).reshape(-1, D)[both[r][1].reshape(-1)]
-            assert torch.equal(full[r * cg.cap:r * cg.cap + n[r]], exp), (step, r)
+            exp = (both[r][0] + offset).reshape(-1, D)[both[r][1].reshape(-1)]
+            assert torch.equal(full[r * cg.cap:r * cg.cap + n[r]].cpu(), exp), (offset, r)
+    for step in range(3):   # the two buffers alternate
+        cg.start(obs_d + step)
+        full, counts = cg.wait()
+        check(full, step)
+    # start() owns the buffer invariant: starts without a wait() in between (each re-uses the pair of two starts
+    # back), then the last one's result; the timing window is bounded
+    for step in range(6):
+        cg.start(obs_d + 10 + step)
+    full, counts = cg.wait()
+    check(full, 15)
+    assert len(cg.events) <= 4
+    # a new mask right after a start(): the in-flight gather is drained before the buffers are replaced
+    cg.start(obs_d + 20)
+    cg.set_mask(ctrl_d)
+    cg.start(obs_d + 21)
+    full, counts = cg.wait()
+    check(full, 21)
     torch.distributed.destroy_process_group()
     print("rank", rank, "ok")
 """)
 
 
-def test_two_rank_gloo_gather_and_reductions(tmp_path):
+def _run_two_ranks(tmp_path, backend):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % ROOT)
     with socket.socket() as s:
@@ -91,8 +117,8 @@ def test_two_rank_gloo_gather_and_reductions(tmp_path):
         port = s.getsockname()[1]
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", GD_TEST_BACKEND=backend,
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -101,6 +127,20 @@ def test_two_rank_gloo_gather_and_reductions(tmp_path):
         outs.append(out)
         assert p.returncode == 0, out
     assert all("ok" in o for o in outs)
+
+
+def test_two_rank_gloo_gather_and_reductions(tmp_path):
+    _run_two_ranks(tmp_path, "gloo")
+
+
+@pytest.mark.gpu
+def test_two_rank_rccl_gather_matches_the_gloo_expectations(tmp_path):
+    """BASELINE configs[3]: the same worker on a 2-rank nccl (= RCCL) group, one GPU per rank -- the first time RCCL sees
+    ObservationGather is under a test, on whatever box has two GPUs (the builder's box has one: skipped there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_two_ranks(tmp_path, "nccl")
 
 
 def test_scene_tiling_matches_reference_dataloader_golden():
