@@ -24,6 +24,7 @@ with the following step (`allgather` in the line; `--gather none` skips it).  `-
 reference's own benchmark CLI (src/headless.cpp:145-155) on stderr.
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -42,6 +43,25 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from gpudrive_lab_amd import sharding, synth  # noqa: E402
+
+# Python's cyclic collector: a full (generation 2) collection walks every container object of the process -- several
+# hundred thousand once torch is imported -- and stops the host for tens of milliseconds at a moment of its own choosing.
+# Inside a 20-step timed region that is longer than the region itself, so the collector is run before each timed
+# stretch and switched off during it (what `timeit` does); every collection that still starts inside one is reported
+# (`gc_ms_in_timed_stretches`).  GPUDRIVE_BENCH_KEEP_GC=1 leaves the collector alone.
+_GC_LOG = []
+_GC_T0 = [0.0]
+
+
+def _gc_callback(phase, info):
+    if phase == "start":
+        _GC_T0[0] = time.perf_counter()
+    else:
+        _GC_LOG.append((_GC_T0[0], time.perf_counter(), info.get("generation", -1)))
+
+
+gc.callbacks.append(_gc_callback)
+KEEP_GC = os.environ.get("GPUDRIVE_BENCH_KEEP_GC") == "1"
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 EPISODE = 91
@@ -158,14 +178,22 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         from gpudrive_lab_amd.episode import EpisodeTracker
         tracker = EpisodeTracker(sim)
 
+    gc_ms = [0.0]
+
     def timed_stretch(k):
+        if not KEEP_GC:
+            gc.collect()
+            gc.disable()
         sharding.barrier(device)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         k = run_steps(sim, batches, all_worlds, args.steps, start=k, tracker=tracker)
         torch.cuda.synchronize(device)
         sharding.barrier(device)
-        return k, time.perf_counter() - t0
+        t1 = time.perf_counter()
+        gc.enable()
+        gc_ms[0] += 1e3 * sum(min(b, t1) - max(a, t0) for a, b, _ in _GC_LOG if b > t0 and a < t1)
+        return k, t1 - t0
 
     k = run_steps(sim, batches, all_worlds, args.warmup, tracker=tracker)
     # ---- 1. the timed region: step() as a user calls it (hipGraph replay, no instrumentation) ----
@@ -191,6 +219,7 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         agent_steps_per_s=total_live * args.steps / elapsed,
         padded_agent_steps_per_s=world * args.worlds * args.agents * args.steps / elapsed,
         timed_region=dict(graph_steps=graph_steps, plain_steps=plain_steps),
+        gc_ms_in_timed_stretches=gc_ms[0],
         worlds=args.worlds,
     )
     names = {0: "k_world_step", 1: "k_map_obs+k_map_rows"}
@@ -426,6 +455,8 @@ def main():
             "timed_region": "step() as a user calls it: the step's kernels replayed from the captured hipGraph (%d graph / %d plain "
                             "steps), no instrumentation" % (primary["timed_region"]["graph_steps"], primary["timed_region"]["plain_steps"]),
             "ms_per_step_events": primary["ms_per_step_events"],
+            "gc_ms_in_timed_stretches": primary["gc_ms_in_timed_stretches"],
+            "python_gc": "left alone (GPUDRIVE_BENCH_KEEP_GC=1)" if KEEP_GC else "collected before and disabled during each timed stretch",
             "kernels_sum_us": primary["kernels_sum_us"],
             "roofline": primary["roofline"],
             "kernels": primary["kernels"],
@@ -438,7 +469,7 @@ def main():
             "cpu_baseline": cpu,
             "other_workloads": [
                 {k: r[k] for k in ("workload", "knn_order", "worlds", "agent_steps_per_s", "padded_agent_steps_per_s", "ms_per_step",
-                                   "ms_per_step_events", "kernels_sum_us", "live_agents_per_rank", "road_entities_per_rank",
+                                   "ms_per_step_events", "gc_ms_in_timed_stretches", "kernels_sum_us", "live_agents_per_rank", "road_entities_per_rank",
                                    "roofline", "kernels", "other_rooflines")}
                 for r in results[1:]],
             "init_seconds": primary["init_seconds"],

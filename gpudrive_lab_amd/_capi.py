@@ -81,7 +81,7 @@ SYMBOLS = [
     "gd_step", "gd_reset", "gd_set_maps", "gd_delete_agents", "gd_tensor", "gd_pack_observations",
     "gd_expert_actions", "gd_advance_log_playback", "gd_episode_step", "gd_sync",
     "gd_set_stream", "gd_attach_bev", "gd_stat",
-    "gd_kernel_timing_enable", "gd_kernel_timing_read", "gd_debug_get_state", "gd_debug_set_state",
+    "gd_kernel_timing_enable", "gd_kernel_timing_read", "gd_debug_get_state", "gd_debug_set_state", "gd_debug_road_path",
     "gd_host_world_build", "gd_host_world_free", "gd_scene_cache_write",
 ]
 
@@ -139,6 +139,7 @@ def lib():
     L.gd_kernel_timing_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.gd_debug_get_state.argtypes = [C.c_void_p, C.c_void_p]
     L.gd_debug_set_state.argtypes = [C.c_void_p, C.c_void_p]
+    L.gd_debug_road_path.argtypes = [C.c_void_p, C.c_void_p]
     L.gd_host_world_build.argtypes = [C.c_char_p, C.POINTER(GdParams), C.c_int32, C.POINTER(C.c_int32), C.c_int32,
                                       C.POINTER(GdHostWorld)]
     L.gd_host_world_free.argtypes = [C.POINTER(GdHostWorld)]

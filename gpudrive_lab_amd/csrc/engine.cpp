@@ -122,6 +122,7 @@ struct gd_sim {
     // signal pool then ran dry in the middle of a timed stretch and one hipLaunchKernel blocked the host for 14 ms --
     // tools/trace_gap.sh -- so that a 20-step wall clock was far above the sum of its kernels.)
     static constexpr size_t kEvRing = 32;
+    bool rk_alloc = false;  // the rank replay's buffers exist (reference order, k-NN)
     bool timing = false;
     std::vector<EventPair> ev_pool[gd::KERNEL_TIMED];
     size_t ev_head[gd::KERNEL_TIMED] = {};  // oldest recorded pair
@@ -545,6 +546,11 @@ struct gd_sim {
         d.boxes = static_cast<const float4 *>(d_boxes);
         HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
         choose_set_schedule();
+        if (rk_alloc) {  // the rank replay runs when some world is large enough for it
+            d.rk_on = 0;
+            for (int w = 0; w < W; w++)
+                if (road_off[w + 1] - road_off[w] >= std::max(d.rk_min_roads, GD_MAP_OBS_K)) d.rk_on = 1;
+        }
         {
             // one BEV workgroup per LIVE agent: a workgroup that only finds out it has no agent still has to be given
             // its 48 KB of LDS and eight waves first
@@ -646,6 +652,20 @@ struct gd_sim {
         std::vector<float> prev(static_cast<size_t>(W) * A * 4, 0.f);
         for (size_t i = 0; i < static_cast<size_t>(W) * A; i++) prev[i * 4 + 2] = INFINITY;
         HIP_CHECK(hipMemcpy(d.knn_prev, prev.data(), prev.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (rk_alloc) {  // likewise no checkpoint of a previous selection: the next one takes the fallback
+            HIP_CHECK(hipMemset(d.cp_hdr, 0, sizeof(float4) * 2 * static_cast<size_t>(W) * A));
+            std::vector<float> bb(static_cast<size_t>(W) * 4);
+            for (int w = 0; w < W; w++) {
+                float lo_x = INFINITY, lo_y = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY;
+                for (size_t r = 0; r * 2 < w_xy[w].size(); r++) {
+                    lo_x = std::min(lo_x, w_xy[w][2 * r]); hi_x = std::max(hi_x, w_xy[w][2 * r]);
+                    lo_y = std::min(lo_y, w_xy[w][2 * r + 1]); hi_y = std::max(hi_y, w_xy[w][2 * r + 1]);
+                }
+                bb[w * 4 + 0] = lo_x; bb[w * 4 + 1] = lo_y; bb[w * 4 + 2] = hi_x; bb[w * 4 + 3] = hi_y;
+            }
+            HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemset(d.rk_fallback, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
+        }
     }
 
     void do_reset(const std::vector<int32_t> &flags) {
@@ -832,6 +852,30 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.grid = s->alloc_internal<gd::GridHdr>(W);
         d.rgrid = s->alloc_internal<gd::GridHdr>(W);
         d.knn_prev = s->alloc_internal<float4>(WA);
+        // rank replay of the reference-order selection (map_obs_rank.hip): a fallback group is one workgroup of k_map_obs
+        d.rk_on = 0;
+        if (GD_MAP_OBS_AW == 32 && cfg->knn_order != GD_KNN_SET_ORDER && params->roadObservationAlgorithm == GD_ROADS_K_NEAREST &&
+            std::getenv("GPUDRIVE_NO_RANK_REPLAY") == nullptr) {
+            d.rk_on = 1;
+            d.rk_min_roads = std::getenv("GPUDRIVE_RANK_MIN_ROADS") ? std::atoi(std::getenv("GPUDRIVE_RANK_MIN_ROADS")) : 1536;
+            s->rk_alloc = true;
+            d.rk_dbg = std::getenv("GPUDRIVE_RANK_DBG") ? std::atoi(std::getenv("GPUDRIVE_RANK_DBG")) : 0;
+            d.rk_E = s->alloc_internal<uint16_t>(WA * GD_RANK_CAP + 64);  // the replay prefetches up to 24 entries past a row
+            d.rk_spc = s->alloc_internal<uint16_t>(WA * GD_RANK_CAP);
+            d.rk_heap = s->alloc_internal<uint32_t>(WA * GD_RANK_HEAP_DW);
+            d.rk_cpe = s->alloc_internal<uint16_t>(WA * GD_RANK_NCP);
+            d.rk_n = s->alloc_internal<int32_t>(WA);
+            d.rk_fallback = s->alloc_internal<int32_t>(WA / 32);
+            d.cp_road = s->alloc_internal<uint16_t>(2 * WA * GD_RANK_NCP);
+            d.cp_T = s->alloc_internal<float>(2 * WA * GD_RANK_NCP);
+            d.cp_hdr = s->alloc_internal<float4>(2 * WA);
+            d.rk_words = s->alloc_internal<uint32_t>(WA * GD_RANK_NCH);
+            d.rk_tl = s->alloc_internal<float>(WA);
+            d.rk_hist = s->alloc_internal<int32_t>(516);
+            d.rk_ticket = s->alloc_internal<int32_t>(WA);
+            d.rk_order = s->alloc_internal<int32_t>(WA);
+            d.road_bbox = s->alloc_internal<float4>(W);
+        }
         for (int i = 0; i < gd_sim::kRing; i++) {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->h_flags[i]), sizeof(int32_t) * W, hipHostMallocDefault));
             HIP_CHECK(hipEventCreateWithFlags(&s->flag_ev[i], hipEventDisableTiming));
@@ -994,7 +1038,11 @@ int gd_attach_bev(gd_sim *s, float *bev) {
 }
 
 int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
-    if (!s || !out || which < 0 || which > 6) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
+    if (!s || !out || which < 0 || which > 7) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
+    if (which == 7) {  // 1: the reference-order road selection takes the rank replay (map_obs_rank.hip)
+        *out = s->d.rk_on;
+        return GD_OK;
+    }
     *out = which == 0 ? s->stat_graph_steps : which == 1 ? s->stat_plain_steps : which == 2 ? s->stat_captures
          : which == 3 ? s->d.set_fused_rows : which == 4 ? s->d.set_apw : which == 5 ? s->d.live_count : GD_MAP_OBS_AW;
     return GD_OK;
@@ -1049,6 +1097,25 @@ int gd_debug_get_state(gd_sim *s, float *out) {
         }
         HIP_CHECK(hipMemcpy(iplane.data(), s->d.collided, WA * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < WA; i++) out[i * 11 + 10] = static_cast<float>(iplane[i]);
+    });
+}
+
+int gd_debug_road_path(gd_sim *s, int32_t *out) {
+    if (!s || !out) return fail(GD_ERR_INVALID, "null argument");
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        const size_t WA = static_cast<size_t>(s->W) * s->A;
+        if (!s->rk_alloc || !s->d.rk_on) {
+            for (size_t i = 0; i < WA; i++) out[i] = -2;
+            return;
+        }
+        HIP_CHECK(hipMemcpy(out, s->d.rk_n, WA * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<int32_t> why(WA);
+        HIP_CHECK(hipMemcpy(why.data(), s->d.rk_ticket, WA * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < WA; i++) {
+            if (out[i] > 0) out[i] = out[i] == (1 << 30) ? -3 : (out[i] & 0xffff);
+            else if (out[i] == -1 && why[i] < -1) out[i] = -10 + (why[i] + 2);  // -10 no checkpoints / small world, -11 overflow, -12 ties
+        }
     });
 }
 

@@ -10,6 +10,13 @@
 #define GD_MAP_OBS_AW 32  // agents per workgroup (= wave) of the reference-order road kernel: 16, 32 or 64
 #endif
 
+// Rank replay of the reference-order road selection (map_obs_rank.hip): candidates per agent, checkpoints per agent,
+// dwords of the heap array handed from the replay to the finishing kernel (K / 2 + 1 pairs, padded to 16 bytes)
+#define GD_RANK_CAP 1280
+#define GD_RANK_NCP 40
+#define GD_RANK_HEAP_DW 104
+#define GD_RANK_NCH 320  // candidate words per agent: 32 roads each, kMaxRoadEntityCount = 10,000
+
 namespace gd {
 
 // the first four are the timed kernels of gd_kernel_timing_read
@@ -81,10 +88,33 @@ struct DevSim {
     const uint16_t *rcell_items;   // local road indices
     const float2 *rcell_xy;        // the (x, y) of those roads, in the same (cell-sorted) order: one coalesced stream per grid row
     float4 *knn_prev;              // [W][A] {x, y, K-th key of the previous selection or +inf, 0}
+    // reference-order road selection, rank replay (map_obs_rank.hip); rk_on = 0: k_map_obs alone selects
+    int rk_on;
+    int rk_min_roads;  // worlds with fewer roads are selected by k_map_obs (the rank path's fixed costs do not pay there)
+    int rk_dbg;  // diagnostic: k_knn_rank stops after phase n (timing only; results are wrong)
+    uint16_t *rk_E;        // [W][A][CAP] rank of every candidate, candidate (= road) order
+    uint16_t *rk_spc;      // [W][A][CAP] sorted slot -> road index
+    uint32_t *rk_heap;     // [W][A][GD_RANK_HEAP_DW] the replayed heap array as rank pairs
+    uint16_t *rk_cpe;      // [W][A][NCP] rank on top of the heap at every checkpoint of this selection
+    int32_t *rk_hist;      // [513] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path
+    int32_t *rk_ticket;    // [W][A] bin << 20 | place inside the bin; -1 = not on the rank path this step
+    int32_t *rk_order;     // [W][A] agents on the rank path, most candidates first
+    uint32_t *rk_words;    // [W][NCH][A] candidate bits of 32 roads (k_knn_scan -> k_knn_rank)
+    float *rk_tl;          // [W][A] the last K-th key of the checkpoint set in use (scales the ranking buckets)
+    const float4 *road_bbox;  // [W] (min x, min y, max x, max y) over the world's roads
+    int32_t *rk_n;         // [W][A] candidates | in-radius candidates << 16; 0 = not on the rank path this step; 1 << 30 = too far from every road
+    int32_t *rk_fallback;  // [W * A / 32] group of 32 agent slots must be selected by k_map_obs this step
+    // checkpoints of the previous selection of every agent: the K-th key (cp_T) that the heap held when the scan reached road
+    // cp_road; cp_hdr = {x, y, number of checkpoints as int bits (0: none usable), 0} where they were recorded
+    // two sets: [0] the previous selection, [1] the selection at the start of the episode (where a reset puts the agent back)
+    uint16_t *cp_road;     // [2][W][A][NCP]
+    float *cp_T;           // [2][W][A][NCP]
+    float4 *cp_hdr;        // [2][W][A]
 };
 
 void launch_kernel(const DevSim &d, hipStream_t st, int which, bool move);
 void launch_map_obs(const DevSim &d, hipStream_t st);  // map_obs.hip
+void launch_map_obs_rank(const DevSim &d, hipStream_t st);  // map_obs_rank.hip
 void launch_bev(const DevSim &d, hipStream_t st);      // bev_lidar.hip
 void launch_lidar(const DevSim &d, hipStream_t st);    // bev_lidar.hip
 void launch_pack_obs(const DevSim &d, hipStream_t st, float *out);  // pack_obs.hip

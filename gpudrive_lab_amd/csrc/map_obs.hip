@@ -392,6 +392,7 @@ struct Drain {
     unsigned int nz = 0;    // ring slots that hold an unread, non-empty word of this agent
     int cw = 0;
     bool has = false;       // (r_cur, xy_cur) is a candidate whose (x, y) has been requested
+    int done = 0;           // candidates replayed or rejected so far
     int r_cur = 0;
     float2 xy_cur = {0.f, 0.f};
     __device__ __forceinline__ bool pending() const { return has || word != 0u || nz != 0u; }
@@ -400,8 +401,12 @@ struct Drain {
 // (gd_math.hpp ego_dist2), re-tested against the live K-th distance and replayed; meanwhile the next one is popped
 // (oldest unread ring word if the current one is used up, its lowest bit) and its (x, y) requested.  `ring` is
 // this agent's column of the ring (slot c at ring[c * AW]), `head` the number of chunks scanned so far.
+// `cpr` / `cpt`: this agent's checkpoint rows (engine.hpp cp_road / cp_T; null when the rank path is off): after every
+// 32nd candidate the K-th key in force is recorded together with the first road it holds for (rounded up to a whole
+// 64-road piece) -- what map_obs_rank.hip bounds the agent's next selection with.
 __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Drain &s, const unsigned int *ring, const float2 *rxy,
-                                            int head, float ex, float ey, float iw, float iz, bool owner) {
+                                            int head, float ex, float ey, float iw, float iz, bool owner,
+                                            unsigned short *cpr, float *cpt) {
     const bool refill = s.word == 0u && s.nz != 0u;
     const unsigned int rot = (s.nz | (s.nz << RING)) >> ((unsigned int)head & (RING - 1));  // bit j: chunk head - RING + j
     const int c_new = head - RING + (__ffs(rot) - 1);
@@ -414,6 +419,13 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
     const float2 xy_nxt = rxy[has_n ? r_nxt : 0];
     const float key = ego_dist2(ex, ey, iw, iz, s.xy_cur.x, s.xy_cur.y);
     if (s.has && key < top.tk[1]) heap.replace_top(owner, key, (unsigned int)s.r_cur, top);  // lanes without an insert sit the block out
+    if (s.has) {
+        s.done++;
+        if (cpr != nullptr && (s.done & 31) == 0 && (s.done >> 5) < GD_RANK_NCP && owner) {
+            cpr[s.done >> 5] = (unsigned short)min(65535, (s.r_cur + 1 + 63) & ~63);
+            cpt[s.done >> 5] = top.tk[1];
+        }
+    }
     s.nz = refill ? s.nz & ~(1u << slot_new) : s.nz;
     s.word = word & (word - 1u);
     s.cw = cw;
@@ -569,6 +581,11 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     const int w = slot / BPW;
     const int a0 = (slot % BPW) * AW;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
+    // after the rank replay (map_obs_rank.hip) only the groups that could not take it are selected here
+    const bool rank_path = d.rk_on != 0 && d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
+    if (rank_path) {
+        if (d.rk_fallback[slot] == 0) return;
+    }
     const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
     const int n = d.shape[w * 2 + 0];
     if (a0 >= n) return;  // rows of padding agents are written at reset (k_init_padding_rows)
@@ -610,6 +627,10 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
         return part;
     };
     int count = 0;
+    // the rank path's checkpoint rows of this agent (recorded here so that the group is back on that path next step)
+    unsigned short *cpr = rank_path && live ? d.cp_road + i * GD_RANK_NCP : nullptr;
+    float *cpt = rank_path && live ? d.cp_T + i * GD_RANK_NCP : nullptr;
+    int cp_count = 0;
 #ifdef GD_STAMPS
     unsigned long long st_scan = 0, st_drain = 0, st_rounds = 0, st_scans = 0, st_init = 0, st_filter = 0, st_wscan = 0, st_wround = 0;
     (void)st_wround;
@@ -643,6 +664,10 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
             Heap::Top top;  // slots 1..7, the deeper chain slots and slot K; top.tk[1] is the K-th distance
             heap.load(top);
             wave_sync();  // every lane of an agent has read slot K before its sentinel value is visible
+            if (cpr != nullptr && owner && live) {  // checkpoint 0: the heap of the first K roads
+                cpr[0] = (unsigned short)((K / 64) * 64);
+                cpt[0] = top.tk[1];
+            }
 #ifdef GD_STAMPS
             st_init = __builtin_amdgcn_s_memtime() - t_begin;
 #endif
@@ -719,7 +744,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 #endif
                 if (pend == 0ull) break;  // nothing pending anywhere; then head == nch
                 // ---- one DRAIN round ----
-                drain_round(heap, top, dr, s_ring + col, rxy, head, ex, ey, iw, iz, owner);
+                drain_round(heap, top, dr, s_ring + col, rxy, head, ex, ey, iw, iz, owner, cpr, cpt);
                 pend = __ballot(dr.pending()) & agents;
 #ifdef GD_STAMPS
                 st_drain += __builtin_amdgcn_s_memtime() - t_s1;
@@ -727,6 +752,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 #endif
             }
             if (owner) heap.store(top);
+            cp_count = min(GD_RANK_NCP, 1 + (dr.done >> 5));
         }
         wave_sync();
         STAMP(t_f0);
@@ -770,6 +796,21 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     // ---- hand the selection to k_map_rows ----
     wave_sync();
     if (owner && live) write_header(d, i, ex, ey, iw, -iz, min(count, K), r0);
+    if (rank_path) {
+        if (owner && live) {
+            d.cp_hdr[i] = make_float4(ex, ey, __int_as_float(cp_count), 0.f);
+            d.rk_n[i] = -1;  // selected here (gd_debug_road_path)
+            if (d.steps[i] == (uint32_t)GD_EPISODE_LEN) {  // the episode's first selection: kept for the next reset
+                const size_t WA = (size_t)d.W * A_T;
+                for (int q = 0; q < cp_count; q++) {
+                    d.cp_road[(WA + i) * GD_RANK_NCP + q] = cpr[q];
+                    d.cp_T[(WA + i) * GD_RANK_NCP + q] = cpt[q];
+                }
+                d.cp_hdr[WA + i] = make_float4(ex, ey, __int_as_float(cp_count), 0.f);
+            }
+        }
+        if (lane == 0) d.rk_fallback[slot] = 0;  // read at the top by every lane of this (only) wave of the group
+    }
     STAMP(t_w0);
     store_selection<A_T>(d, w, a0, min(AW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; }, lane, 64);
     if (lane == 0) d.wave_cost[slot] = (unsigned int)min(__builtin_amdgcn_s_memtime() - t_launch, 0xffffffffull);
@@ -1220,6 +1261,7 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4, false>), grid, dim3(256), 0, st, d);
         else hipLaunchKernelGGL((k_map_obs_set<128, 4, false>), grid, dim3(256), 0, st, d);
     } else {
+        if (d.rk_on && d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST) launch_map_obs_rank(d, st);
         const dim3 grid(d.W * (d.A / AW));
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64>), grid, dim3(64), 0, st, d);
         else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);

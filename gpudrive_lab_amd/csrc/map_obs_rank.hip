@@ -1,0 +1,811 @@
+// Road observations in the reference's row order, fast path: the heap history replayed on 16-bit RANKS.
+//
+// selectKNearestRoadEntities (reference src/knn.hpp:103-158) pushes every road that is closer than the running K-th
+// distance through an SGI binary heap (src/binary_heap.hpp) and returns the heap ARRAY, so the output order depends
+// on every insert that ever happened.  map_obs.hip replays that history on fp32 keys + u16 indices (1200 B of LDS per
+// agent: 128 agents per CU, one lone wave per SIMD, two generations of workgroups at 1024 x 64).  The heap's
+// behaviour depends only on the OUTCOME of key comparisons, so this file replays it on ranks:
+//
+//   k_knn_scan +  The agent's CANDIDATES (scan: one lane per agent over every road of the world; rank: one wave per agent
+//   k_knn_rank    over its candidates): roads 0..K-1 plus every later
+//                 road whose key is below a bound that provably is not smaller than the K-th distance the heap holds when
+//                 the reference reaches that road.  The bound comes from the previous selection of the same agent: the
+//                 K-th smallest distance over a fixed prefix of roads is 1-Lipschitz in the agent's position, and the
+//                 previous replay recorded it at checkpoints (every 32 candidates).  A road that is not a candidate fails
+//                 the reference's `cmp(current, heap[0])` test (src/knn.hpp:138-143) and never touches the heap, so
+//                 replaying the candidates alone reproduces the heap exactly; candidates that are not inserts fail the
+//                 same test in the replay.  The candidates' exact keys (gd_math.hpp ego_dist2, the reference's
+//                 arithmetic) are ranked: e = (number of candidates with a smaller key + 1) << 5 | (index among the
+//                 candidates with an EQUAL key).  key_a < key_b  <=>  (e_a >> 5) < (e_b >> 5), equal keys compare
+//                 equal like in the reference, and e still names the candidate.  400 B of heap per agent instead of 1200.
+//   k_knn_replay  one lane per agent, 64 agents per wave, the heap as u16 pairs in LDS: make_heap, then
+//                 pop_heap / push_heap per insert, statement for statement the reference's algorithm.
+//   k_knn_finish  one wave per agent: ranks back to road indices, radiusFilter (src/knn.hpp:83-97), the checkpoints'
+//                 K-th distances for the next step, hand-over to k_map_rows.
+//
+// An agent without usable checkpoints (first selection after a reset or a map change, a teleport), with more
+// candidates than CAP, with more than 32 equal keys, or in a world with fewer than K roads raises the fallback flag of its
+// group of 32 agents; k_map_obs (map_obs.hip) then selects for that group as before -- the same rows by construction --
+// and records checkpoints, so the group is back on this path at the next step.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "engine.hpp"
+#include "gd_math.hpp"
+
+namespace gd {
+
+namespace {
+
+constexpr int K = GD_MAP_OBS_K;
+constexpr int CAP = GD_RANK_CAP;   // candidates per agent
+constexpr int NCP = GD_RANK_NCP;   // checkpoints per agent
+constexpr int TILE = 32;           // candidates between checkpoints
+constexpr int NB = 1280;           // ranking buckets
+constexpr int NLIN = 768;          // of which linear in the key (up to 1.5 x the previous K-th key); the other 512 take
+                                   // the eight octaves above that, 64 each: about one candidate per bucket on either side
+static_assert(K + (NCP - 1) * TILE >= CAP, "a checkpoint slot for every tile of candidates");
+static_assert(CAP % 64 == 0 && NB % 64 == 0 && CAP < 2047, "geometry; less + 1 fits 11 bits");
+constexpr int RK_FAR = 1 << 30;    // rk_n: no road of the world can be within the agent's radius
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// inclusive prefix sum over the 64 lanes (DPP row shifts and row broadcasts)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// key comparison on ranks: key(a) < key(b)  <=>  (a >> 5) < (b >> 5)  <=>  (a | 31) < b.  0 is "below everything".
+__device__ __forceinline__ bool rank_lt(unsigned int a, unsigned int b) { return (a | 31u) < b; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_knn_scan: one lane per agent, one workgroup (4 waves) per 64 agent slots of a world.  Every road of the world is tested
+// against every agent's bound with the cheap form |p - e|^2 < bound * margin (the margin covers rounding and the squared
+// norm of the stored quaternion, like k_map_obs's scan), 32 roads per candidate word; the roads come through LDS as
+// broadcast reads, so a road costs a wave one LDS instruction and five vector instructions for 64 agents.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SCAN_TILE = 2048;  // roads staged in LDS at a time
+
+template <int A_T>
+__global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
+    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
+    constexpr int HALVES = A_T / 64;
+    const int w = blockIdx.x / HALVES, a0 = (blockIdx.x % HALVES) * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = d.shape[w * 2 + 0];
+    if (a0 >= n) return;
+    const int a = a0 + lane;
+    const bool live = a < n;
+    const size_t i = (size_t)w * A_T + a;
+    const size_t WA = (size_t)d.W * A_T;
+    const int r0 = d.road_off[w];
+    const int R = d.road_off[w + 1] - r0;
+
+    __shared__ float2 s_xy[SCAN_TILE];
+    __shared__ unsigned short s_first[NCP][64];  // checkpoint q of lane l: first road it holds for ...
+    __shared__ float s_thr[NCP][64];             // ... and the scan threshold it gives
+    __shared__ int s_ncp[64];                    // checkpoints of lane l; 0: the lane takes no part in the scan
+
+    float ex = 0.f, ey = 0.f;
+    if (live) { ex = d.px[i]; ey = d.py[i]; }
+    if (wave == 0) {
+        int ncp = 0;
+        if (live) {
+            // too far from every road of the world for any to be within the radius: no rows (a finished agent parked
+            // at the padding position, src/sim.cpp:333-343)
+            const float4 bb = d.road_bbox[w];
+            const float ddx = fmaxf(fmaxf(bb.x - ex, ex - bb.z), 0.f), ddy = fmaxf(fmaxf(bb.y - ey, ey - bb.w), 0.f);
+            const float far = d.p.observationRadius * 1.01f + 1.f;
+            int state = 1, reason = -1;
+            if (R >= K && ddx * ddx + ddy * ddy > far * far) {
+                state = RK_FAR;
+            } else {
+                // the previous selection's checkpoints, or those of the episode's first selection (a reset puts the agent
+                // back where that one was made): whichever was recorded closer to where the agent is now
+                const float4 h0 = d.cp_hdr[i], h1 = d.cp_hdr[WA + i];
+                const int n0 = __float_as_int(h0.z), n1 = __float_as_int(h1.z);
+                const float m0 = n0 > 0 ? sqrtf((ex - h0.x) * (ex - h0.x) + (ey - h0.y) * (ey - h0.y)) : __builtin_inff();
+                const float m1 = n1 > 0 ? sqrtf((ex - h1.x) * (ex - h1.x) + (ey - h1.y) * (ey - h1.y)) : __builtin_inff();
+                const int set = m1 < m0 ? 1 : 0;
+                const float move = set ? m1 : m0;
+                ncp = (R >= K && R >= d.rk_min_roads) ? (set ? n1 : n0) : 0;  // small worlds: k_map_obs is as fast
+                if (ncp <= 0) {
+                    state = 0;
+                    ncp = 0;
+                    reason = -2;  // no usable checkpoints, or a world below rk_min_roads
+                    d.rk_fallback[i / 32] = 1;
+                } else {
+                    const float iw = d.qw[i], iz = d.qz[i];
+                    const float z2 = iz * iz;
+                    const float det = (1.f - 2.f * z2) * (1.f - 2.f * z2) + 4.f * z2 * (iw * iw);
+                    const float margin = 1.00001f / fminf(det, 1.f);
+                    const unsigned short *cr = d.cp_road + ((size_t)set * WA + i) * NCP;
+                    const float *ct = d.cp_T + ((size_t)set * WA + i) * NCP;
+                    float t = 1.f;
+                    for (int q = 0; q < ncp; q++) {
+                        t = ct[q];
+                        const float reach = sqrtf(t) * 1.0001f + move * 1.0001f + 1e-3f;
+                        float thr = reach * reach * 1.0001f * margin;
+                        if (!(thr >= 0.f)) thr = __builtin_inff();  // an unusable entry bounds nothing
+                        s_first[q][lane] = cr[q];
+                        s_thr[q][lane] = thr;
+                    }
+                    d.rk_tl[i] = t;  // the last K-th key: scales the ranking buckets
+                }
+            }
+            d.rk_n[i] = state;
+            d.rk_ticket[i] = reason;  // k_knn_rank takes a ticket (>= 0) once the agent's ranks exist; < -1: why it fell back
+            if (state == RK_FAR) ncp = 0;
+        }
+        s_ncp[lane] = ncp;
+    }
+    __syncthreads();
+    const int ncp = s_ncp[lane];
+    int q = -1;  // checkpoint in force for this lane
+    const int nch = (R + 31) >> 5;
+    uint32_t *words = d.rk_words + (size_t)w * GD_RANK_NCH * A_T + a;
+    for (int tile = 0; tile < R; tile += SCAN_TILE) {
+        __syncthreads();
+        for (int r = tile + tid; r < min(R, tile + SCAN_TILE); r += 256) s_xy[r - tile] = d.road_xy[r0 + r];
+        __syncthreads();
+        const int c_end = min(nch, (tile + SCAN_TILE) >> 5);
+#pragma clang loop unroll(disable)
+        for (int c = (tile >> 5) + wave; c < c_end; c += 4) {
+            const int base = c << 5;
+            while (q + 1 < ncp && (int)s_first[q + 1][lane] <= base) q++;
+            const float thr = q >= 0 ? s_thr[q][lane] : __builtin_inff();
+            const float2 *t = s_xy + (base - tile);
+            unsigned int wd = 0;
+#pragma unroll
+            for (int k = 31; k >= 0; k--) {
+                const float2 xy = t[k];  // the same address in every lane: a broadcast read
+                const float dx = xy.x - ex, dy = xy.y - ey;
+                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                wd = __builtin_amdgcn_alignbit(wd, __float_as_uint(d2 - thr), 31);  // (wd << 1) | (d2 < thr)
+            }
+            if (base < K) wd |= K - base >= 32 ? 0xffffffffu : (1u << (K - base)) - 1u;  // roads below K regardless
+            const int left = R - base;
+            if (left < 32) wd &= (1u << left) - 1u;
+            if (ncp > 0) words[(size_t)c * A_T] = wd;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_knn_rank: one wave per live agent.  Candidate words -> candidate list, exact keys, ranks.
+// ------------------------------------------------------------------------------------------------------------------
+struct RankLds {
+    float ckey[CAP];             // candidate keys, road order; then every candidate's rank
+    unsigned short cidx[CAP];    // candidate road indices, road order
+    float skey[CAP];             // the keys again, bucket order; then sorted slot -> road index
+    unsigned short spos[CAP];    // bucket order -> candidate position
+    int cnt[NB];                 // bucket counters, then cursors: after the scatter cnt[b] is the END of bucket b
+};
+
+// What the ranking of one agent reads from global memory before it can start, fetched while the previous agent of the
+// wave is being ranked (the fetches are a chain of dependent loads, several microseconds end to end).
+constexpr int WPL = GD_RANK_NCH / 64;  // candidate words per lane
+struct RankIn {
+    int i, state, r0, R;
+    float ex, ey, iw, iz, t_last;
+    unsigned int wd[WPL];
+};
+template <int A_T>
+__device__ __forceinline__ RankIn rank_fetch(const DevSim &d, int li, int lane) {
+    RankIn in;
+    in.i = li < d.live_count ? d.live_list[li] : 0;
+    in.state = li < d.live_count ? d.rk_n[in.i] : 0;
+    const int w = in.i / A_T, a = in.i - w * A_T;
+    in.r0 = d.road_off[w];
+    in.R = d.road_off[w + 1] - in.r0;
+    in.ex = d.px[in.i]; in.ey = d.py[in.i];
+    in.iw = d.qw[in.i]; in.iz = -d.qz[in.i];  // the INVERSE rotation
+    in.t_last = d.rk_tl[in.i];
+    const int nch = (in.R + 31) >> 5;
+    const uint32_t *words = d.rk_words + (size_t)w * GD_RANK_NCH * A_T + a;
+#pragma unroll
+    for (int k = 0; k < WPL; k++) {
+        const int c = k * 64 + lane;
+        in.wd[k] = (in.state == 1 && c < nch) ? words[(size_t)c * A_T] : 0u;
+    }
+    return in;
+}
+
+template <int A_T>
+__device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds &L) {
+    if (in.state != 1) return;  // fallback or too far from every road (k_knn_scan)
+    const int i = in.i, r0 = in.r0, R = in.R;
+    const int group = i / 32;  // 32 consecutive agent slots of a world: the fallback unit (a workgroup of k_map_obs)
+    float *ckey = L.ckey, *skey = L.skey;
+    unsigned short *cidx = L.cidx, *spos = L.spos;
+    int *cnt = L.cnt;
+
+    // ---- candidate words -> road indices in ascending order ----
+    const int nch = (R + 31) >> 5;
+    int nin = 0;
+#pragma unroll
+    for (int k = 0; k < WPL; k++) {
+        if (k * 64 >= nch || nin > CAP) break;  // wave-uniform
+        const int c = k * 64 + lane;
+        unsigned int wd = in.wd[k];
+        const int pc = __popc(wd);
+        const int incl = wave_incl_scan(pc);
+        int pos = nin + incl - pc;
+        nin += __builtin_amdgcn_readlane(incl, 63);
+        if (nin > CAP) break;  // wave-uniform
+        while (wd) {
+            cidx[pos++] = (unsigned short)((c << 5) + __ffs(wd) - 1);
+            wd &= wd - 1u;
+        }
+    }
+    if (nin > CAP) {
+        if (lane == 0) {
+            d.rk_n[i] = 0;
+            d.rk_ticket[i] = -3;  // more candidates than the buffer holds
+            d.rk_fallback[group] = 1;
+        }
+        return;
+    }
+    wave_sync();
+    if (d.rk_dbg == 1) return;
+    // ---- exact keys (gd_math.hpp ego_dist2: the reference's arithmetic) ----
+    const float ex = in.ex, ey = in.ey, iw = in.iw, iz = in.iz;
+    const float kmax = d.radius_key_max;
+    const float2 *rxy = d.road_xy + r0;
+    int nle = 0;
+#pragma clang loop unroll_count(4)
+    for (int p = lane; p < nin; p += 64) {
+        const float2 xy = rxy[cidx[p]];
+        const float key = ego_dist2(ex, ey, iw, iz, xy.x, xy.y);
+        ckey[p] = key;
+        nle += key <= kmax ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nle += __shfl_xor(nle, off);
+    const float t_last = in.t_last;
+    wave_sync();
+    if (d.rk_dbg == 2) return;
+
+    // ---- ranks.  Counting sort into NB buckets (a monotone function of the key: linear up to 1.5 x the previous
+    // K-th key, where most candidates lie, logarithmic beyond), then the exact order inside each bucket.  Every pass
+    // takes four candidates per lane at a time: the passes are chains of LDS round trips, and four independent chains
+    // hide each other's latency ----
+    for (int b = lane; b < NB; b += 64) cnt[b] = 0;
+    wave_sync();
+    const float split = (t_last > 0.f && t_last < 1e30f) ? t_last * 1.5f : 1.f;
+    const float lin_scale = (float)NLIN / split;
+    const unsigned int split_bits = __float_as_uint(split);
+    auto bucket_of = [&](float key) -> int {
+        if (key < split) return min(NLIN - 1, max(0, (int)(key * lin_scale)));
+        return NLIN + (int)min((unsigned int)(NB - NLIN - 1), (__float_as_uint(key) - split_bits) >> 17);  // 64 buckets per octave
+    };
+    constexpr int U = 4;
+#pragma clang loop unroll(disable)
+    for (int p0 = lane; p0 < nin; p0 += 64 * U) {
+        float k[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) k[u] = p0 + 64 * u < nin ? ckey[p0 + 64 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (p0 + 64 * u < nin) atomicAdd(&cnt[bucket_of(k[u])], 1);
+    }
+    wave_sync();
+    {
+        // exclusive prefix over the buckets: lane l owns buckets l * (NB / 64) ..
+        constexpr int BPL = NB / 64;
+        int own[BPL], sum = 0;
+#pragma unroll
+        for (int k = 0; k < BPL; k++) { own[k] = cnt[lane * BPL + k]; sum += own[k]; }
+        int run = wave_incl_scan(sum) - sum;
+#pragma unroll
+        for (int k = 0; k < BPL; k++) { cnt[lane * BPL + k] = run; run += own[k]; }
+    }
+    wave_sync();
+    if (d.rk_dbg == 3) return;
+#pragma clang loop unroll(disable)
+    for (int p0 = lane; p0 < nin; p0 += 64 * U) {
+        float k[U];
+        int sl[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) k[u] = p0 + 64 * u < nin ? ckey[p0 + 64 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; u++) sl[u] = p0 + 64 * u < nin ? atomicAdd(&cnt[bucket_of(k[u])], 1) : 0;  // any order inside the bucket
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (p0 + 64 * u < nin) {
+                skey[sl[u]] = k[u];
+                spos[sl[u]] = (unsigned short)(p0 + 64 * u);
+            }
+        }
+    }
+    wave_sync();
+    if (d.rk_dbg == 4) return;
+    bool too_many_ties = false;
+    unsigned int *cres = reinterpret_cast<unsigned int *>(ckey);  // a candidate's result replaces its key
+#pragma clang loop unroll(disable)
+    for (int p0 = lane; p0 < nin; p0 += 64 * U) {
+        float k[U];
+        int s0[U], s1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) k[u] = p0 + 64 * u < nin ? ckey[p0 + 64 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int b = bucket_of(k[u]);
+            s0[u] = b ? cnt[b - 1] : 0;
+            s1[u] = p0 + 64 * u < nin ? cnt[b] : s0[u];
+        }
+        // the first four members of every bucket at once (most buckets hold fewer), the rest in a loop
+        constexpr int M = 4;
+        float mk[U][M];
+        int mp[U][M];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                const int m = min(s0[u] + j, CAP - 1);
+                mk[u][j] = skey[m];
+                mp[u][j] = spos[m];
+            }
+        int less[U], tie[U], longest = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int p = p0 + 64 * u;
+            less[u] = s0[u];
+            tie[u] = 0;
+            longest = max(longest, s1[u] - s0[u]);
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                const bool in = s0[u] + j < s1[u];
+                less[u] += (in && mk[u][j] < k[u]) ? 1 : 0;
+                tie[u] += (in && mk[u][j] == k[u] && mp[u][j] < p) ? 1 : 0;
+            }
+        }
+        // larger buckets: all four candidates of the lane advance together (one LDS round trip per step, not four)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off));
+        if (d.rk_dbg == 7) longest = 0;
+        for (int j = M; j < longest; j++) {
+            float mkk[U];
+            int mpp[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int m = min(s0[u] + j, CAP - 1);
+                mkk[u] = skey[m];
+                mpp[u] = spos[m];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool in = s0[u] + j < s1[u];
+                less[u] += (in && mkk[u] < k[u]) ? 1 : 0;
+                tie[u] += (in && mkk[u] == k[u] && mpp[u] < p0 + 64 * u) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int p = p0 + 64 * u;
+            if (p < nin) {
+                too_many_ties = too_many_ties || tie[u] > 31;
+                cres[p] = (unsigned int)(((less[u] + 1) << 5) | (tie[u] & 31));
+            }
+        }
+    }
+    wave_sync();
+    if (d.rk_dbg == 5) return;
+    if (__ballot(too_many_ties) != 0ull) {
+        if (lane == 0) {
+            d.rk_n[i] = 0;
+            d.rk_ticket[i] = -4;  // more than 32 candidates with one key
+            d.rk_fallback[group] = 1;
+        }
+        return;
+    }
+    unsigned short *spc = reinterpret_cast<unsigned short *>(skey);  // sorted slot -> road index; the bucket-order keys are done with
+#pragma clang loop unroll_count(4)
+    for (int p = lane; p < nin; p += 64) {
+        const unsigned int e = cres[p];
+        d.rk_E[(size_t)i * CAP + p] = (unsigned short)e;
+        spc[(int)(e >> 5) - 1 + (int)(e & 31u)] = cidx[p];
+    }
+    wave_sync();
+    for (int s = lane; s < nin; s += 64) d.rk_spc[(size_t)i * CAP + s] = spc[s];
+    // where this selection's checkpoints start to apply (their K-th distances are filled in by k_knn_finish):
+    // checkpoint 0 is the heap of the first K roads (road indices below K are candidates regardless), checkpoint q
+    // the heap after candidate K + 32 q - 1, which holds for every road behind that candidate; rounded up to whole
+    // 64-road pieces of the scan
+    const int ncp_new = 1 + (nin - K) / TILE;
+    if (lane < ncp_new) {
+        int first = (K / 64) * 64;
+        if (lane > 0) first = ((int)cidx[K + TILE * lane - 1] + 1 + 63) & ~63;
+        d.cp_road[(size_t)i * NCP + lane] = (unsigned short)min(first, 65535);
+    }
+    if (lane == 0) {
+        d.rk_n[i] = nin | (nle << 16);
+        const int bin = 255 - min(255, (nin - K) / 5);  // longest first
+        d.rk_ticket[i] = bin << 20 | atomicAdd(&d.rk_hist[bin], 1);
+    }
+}
+
+// A wave ranks several agents in turn: tens of thousands of one-agent workgroups cost more in workgroup launches (each is
+// handed its 20 KB of LDS first) than in work.
+template <int A_T>
+__global__ __launch_bounds__(64) void k_knn_rank(DevSim d) {
+    if (d.gate_any && *d.any_reset == 0) return;
+    __shared__ RankLds L;
+    RankIn cur = rank_fetch<A_T>(d, blockIdx.x, threadIdx.x);
+    for (int li = blockIdx.x; li < d.live_count; li += gridDim.x) {
+        const RankIn nxt = rank_fetch<A_T>(d, li + gridDim.x, threadIdx.x);
+        rank_agent<A_T>(d, cur, threadIdx.x, L);
+        wave_sync();  // the LDS buffers change hands
+        cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_knn_replay
+// ------------------------------------------------------------------------------------------------------------------
+// The heap of lane `l`: slots 1..K (1-based; the reference's array index is slot - 1) as u16 ranks, two per dword:
+// pair j = (slot 2j, slot 2j + 1) at s_pair[j * 64 + l], so the children of slot g are pair g.  Slot K + 1 and, during
+// the replay, slot K (whose element lives in a register) hold 0, which is below every rank.
+constexpr int AWR = 32;  // agents per wave of the replay: two waves per SIMD at 1024 x 64 cover each other's LDS round trips
+struct RankHeap {
+    unsigned int *pr;  // this lane's column
+    __device__ __forceinline__ unsigned int pair(int j) const { return pr[j * AWR]; }
+    __device__ __forceinline__ unsigned int get(int g) const {
+        return reinterpret_cast<const unsigned short *>(pr + (g >> 1) * AWR)[g & 1];
+    }
+    __device__ __forceinline__ void set(int g, unsigned int v) const {
+        reinterpret_cast<unsigned short *>(pr + (g >> 1) * AWR)[g & 1] = (unsigned short)v;
+    }
+};
+
+// Replay order: the agents on the rank path sorted by candidate count, longest first (counting sort over 256 bins: k_knn_rank
+// takes a ticket in its bin, this kernel turns the bin counts into starts, k_knn_order places the agents).  A wave's rounds are
+// its longest agent's, so agents of similar length share a wave; which wave an agent rides never changes its result.
+__global__ __launch_bounds__(256) void k_knn_bins(DevSim d) {
+    if (d.gate_any && *d.any_reset == 0) return;
+    __shared__ int s_part[4];
+    const int t = threadIdx.x;
+    const int c = d.rk_hist[t];
+    const int incl = wave_incl_scan(c);
+    if ((t & 63) == 63) s_part[t >> 6] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < (t >> 6); k++) before += s_part[k];
+    d.rk_hist[256 + t] = before + incl - c;  // start of bin t
+    d.rk_hist[t] = 0;                        // ready for the next selection
+    if (t == 255) d.rk_hist[512] = before + incl;  // agents on the rank path
+}
+
+__global__ __launch_bounds__(256) void k_knn_order(DevSim d) {
+    if (d.gate_any && *d.any_reset == 0) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.live_count) return;
+    const int i = d.live_list[t];
+    const int ticket = d.rk_ticket[i];
+    if (ticket < 0) return;  // not on the rank path
+    d.rk_order[d.rk_hist[256 + (ticket >> 20)] + (ticket & 0xfffff)] = i;
+}
+
+__global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
+    if (d.gate_any && *d.any_reset == 0) return;
+    const int lane = threadIdx.x;
+    const int li = blockIdx.x * AWR + lane;
+    constexpr int NPAIR = 128;  // pairs 0..K/2 hold the heap; K/2 + 1 .. 127 stay 0: the "children" of slots beyond the heap
+    __shared__ unsigned int s_pair[NPAIR * AWR];
+    const RankHeap H{s_pair + (lane % AWR)};
+    int i = 0, n = 0;
+    if (lane < AWR && li < d.rk_hist[512]) {
+        i = d.rk_order[li];
+        n = d.rk_n[i] & 0xffff;
+        if (d.rk_fallback[i / 32] != 0) n = 0;  // the whole group is selected by k_map_obs
+    }
+    const bool on = n >= K;  // never true for the upper lanes, which share LDS columns with the lower ones
+    if (__ballot(on) == 0ull) return;
+    const unsigned short *E = d.rk_E + (size_t)i * CAP;
+
+    // ---- the first K candidates are roads 0..K-1 in order (src/knn.hpp:112-120) ----
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(E);
+        if (lane < AWR) {
+            H.pr[0] = 0u;
+            for (int j = K / 2; j < NPAIR; j++) H.pr[j * AWR] = 0u;
+        }
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < K / 8; k++) {
+            const uint4 v = on ? src[k] : make_uint4(0u, 0u, 0u, 0u);
+            const unsigned int wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (lane < AWR) {
+                    H.set(k * 8 + c * 2 + 1, wd[c] & 0xffffu);
+                    H.set(k * 8 + c * 2 + 2, wd[c] >> 16);
+                }
+            }
+        }
+    }
+    // ---- make_heap, src/binary_heap.hpp:170-185: parents K/2 .. 1, each __adjust_heap(hole, len = K, value) ----
+    if (on) {
+#pragma clang loop unroll(disable)
+        for (int g = K / 2; g >= 1; g--) {
+            const unsigned int x = H.get(g);
+            int h = g;
+            while (2 * h + 1 <= K) {  // both children exist: take the larger one (the right one unless it is smaller)
+                const unsigned int p2 = H.pair(h);
+                const unsigned int kl = p2 & 0xffffu, kr = p2 >> 16;
+                const bool right = !rank_lt(kr, kl);
+                H.set(h, right ? kr : kl);
+                h = 2 * h + (right ? 1 : 0);
+            }
+            if (2 * h == K) {  // a lone left child
+                H.set(h, H.get(K));
+                h = K;
+            }
+            while (h > g) {  // __push_heap towards the sift's own top
+                const unsigned int pv = H.get(h >> 1);
+                if (!rank_lt(pv, x)) break;
+                H.set(h, pv);
+                h >>= 1;
+            }
+            H.set(h, x);
+        }
+    }
+    unsigned int r[8];             // slots 1..7 (tree levels 0..2) live in registers during the replay; r[1] is heap[0]
+#pragma unroll
+    for (int j = 1; j < 8; j++) r[j] = H.get(j);
+    unsigned int last = H.get(K);  // heap[K - 1], kept in a register as well
+    if (lane < AWR) H.set(K, 0u);
+    unsigned short *cpe = d.rk_cpe + (size_t)i * NCP;
+    if (on) cpe[0] = (unsigned short)r[1];
+
+    // ---- roads K.. : pop_heap + replace last + push_heap per insert (src/knn.hpp:128-151) ----
+    int nmax = n;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
+    const uint4 *blocks = reinterpret_cast<const uint4 *>(E + K);  // K * 2 bytes: 16-byte aligned
+    uint4 cur = on ? blocks[0] : make_uint4(0u, 0u, 0u, 0u);
+    uint4 nxt = on ? blocks[1] : make_uint4(0u, 0u, 0u, 0u);
+#pragma clang loop unroll(disable)
+    for (int p = K; p < nmax; p++) {
+        const int t = p - K;
+        const unsigned int y = cur.x & 0xffffu;
+        cur.x = (cur.x >> 16) | (cur.y << 16);
+        cur.y = (cur.y >> 16) | (cur.z << 16);
+        cur.z = (cur.z >> 16) | (cur.w << 16);
+        cur.w = cur.w >> 16;
+        if ((t & 7) == 7) {
+            cur = nxt;
+            if (on) nxt = blocks[(t >> 3) + 2];  // may run past this agent's candidates: the array ends in slack
+        }
+        if (p < n && rank_lt(y, r[1])) {
+            // pop_heap: the hole goes from the root to the bottom of the (K - 1)-element heap along the larger child.
+            // Levels 0 and 1 are decided in registers (slots 1..7 live there during the replay); below that two levels
+            // per LDS round trip: a node's children pair and both grandchildren pairs are fetched together (pairs beyond
+            // the heap hold 0, which loses every comparison).  The ancestors of slot K that the push will meet are
+            // requested now as well and patched where the pop's path went through them.
+            int g[8];
+            unsigned int ck[7];
+            const bool right0 = !rank_lt(r[3], r[2]);
+            ck[0] = right0 ? r[3] : r[2];
+            const unsigned int hl = right0 ? r[6] : r[4], hr = right0 ? r[7] : r[5];
+            const bool right1 = !rank_lt(hr, hl);
+            ck[1] = right1 ? hr : hl;
+            g[0] = 1;
+            g[1] = 2 + (right0 ? 1 : 0);
+            g[2] = 2 * g[1] + (right1 ? 1 : 0);
+            const unsigned int q12 = H.get(12), q25 = H.get(25), q50 = H.get(50), q100 = H.get(100);
+#pragma unroll
+            for (int l = 2; l < 6; l += 2) {
+                const unsigned int pc = H.pair(g[l]), pl = H.pair(2 * g[l]), pr2 = H.pair(2 * g[l] + 1);
+                const unsigned int kl = pc & 0xffffu, kr = pc >> 16;
+                const bool right = !rank_lt(kr, kl);
+                ck[l] = right ? kr : kl;
+                g[l + 1] = 2 * g[l] + (right ? 1 : 0);
+                const unsigned int pg = right ? pr2 : pl;
+                const unsigned int gl = pg & 0xffffu, gr = pg >> 16;
+                const bool right2 = !rank_lt(gr, gl);
+                ck[l + 1] = right2 ? gr : gl;
+                g[l + 2] = 2 * g[l + 1] + (right2 ? 1 : 0);
+            }
+            {
+                const unsigned int pc = H.pair(g[6]);
+                const unsigned int kl = pc & 0xffffu, kr = pc >> 16;
+                const bool right = !rank_lt(kr, kl);
+                ck[6] = right ? kr : kl;
+                g[7] = 2 * g[6] + (right ? 1 : 0);
+            }
+            // the old last element climbs back from the leaf hole past every moved child that is smaller; the moved
+            // children are non-increasing down the path, so "it passes level l" is monotone in l
+            bool c[7];
+#pragma unroll
+            for (int l = 0; l < 7; l++) c[l] = rank_lt(ck[l], last);
+            unsigned int v[8];
+#pragma unroll
+            for (int l = 0; l < 8; l++) {
+                if (l == 0) v[l] = c[0] ? last : ck[0];
+                else if (l == 7) v[l] = c[6] ? ck[6] : last;
+                else v[l] = c[l - 1] ? ck[l - 1] : (c[l] ? last : ck[l]);
+            }
+            r[1] = v[0];
+            r[2] = right0 ? r[2] : v[1];
+            r[3] = right0 ? v[1] : r[3];
+#pragma unroll
+            for (int j = 4; j < 8; j++) r[j] = g[2] == j ? v[2] : r[j];
+#pragma unroll
+            for (int l = 3; l < 8; l++)
+                if (l < 6 || g[l] < K) H.set(g[l], v[l]);  // levels 3..5 are always inside the heap
+            // push_heap: the new element climbs from slot K along 100, 50, 25, 12, 6, 3, 1
+            static_assert(K == 200, "ancestor chain of slot K");
+            const unsigned int qv[7] = {r[1], r[3], r[6], g[3] == 12 ? v[3] : q12, g[4] == 25 ? v[4] : q25,
+                                        g[5] == 50 ? v[5] : q50, g[6] == 100 ? v[6] : q100};
+            bool pp[7];
+#pragma unroll
+            for (int u = 0; u < 7; u++) pp[u] = rank_lt(qv[u], y);
+            r[1] = pp[0] ? y : r[1];
+            r[3] = pp[1] ? (pp[0] ? qv[0] : y) : r[3];
+            r[6] = pp[2] ? (pp[1] ? qv[1] : y) : r[6];
+            constexpr int chain[7] = {1, 3, 6, 12, 25, 50, 100};
+#pragma unroll
+            for (int u = 3; u < 7; u++)
+                if (pp[u]) H.set(chain[u], pp[u - 1] ? qv[u - 1] : y);
+            last = pp[6] ? qv[6] : y;
+        }
+        if (((t + 1) & (TILE - 1)) == 0 && p < n) cpe[(t + 1) / TILE] = (unsigned short)r[1];
+    }
+    // ---- the heap array, slot order, for k_knn_finish ----
+    if (lane < AWR) {
+        H.set(K, last);
+#pragma unroll
+        for (int j = 1; j < 8; j++) H.set(j, r[j]);
+    }
+    if (on) {
+        unsigned int *out = d.rk_heap + (size_t)i * GD_RANK_HEAP_DW;
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < GD_RANK_HEAP_DW; j += 4) {
+            uint4 v;
+            v.x = j + 0 <= K / 2 ? H.pair(j + 0) : 0u;
+            v.y = j + 1 <= K / 2 ? H.pair(j + 1) : 0u;
+            v.z = j + 2 <= K / 2 ? H.pair(j + 2) : 0u;
+            v.w = j + 3 <= K / 2 ? H.pair(j + 3) : 0u;
+            *reinterpret_cast<uint4 *>(out + j) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_knn_finish
+// ------------------------------------------------------------------------------------------------------------------
+template <int A_T>
+__global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
+    if (d.gate_any && *d.any_reset == 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = blockIdx.x * 4 + wave;
+    if (li >= d.live_count) return;
+    const int i = d.live_list[li];
+    if (d.rk_fallback[i / 32] != 0) return;  // k_map_obs selects for this group
+    const int packed = d.rk_n[i];
+    const int w = i / A_T;
+    const int r0 = d.road_off[w];
+    const float ex = d.px[i], ey = d.py[i];
+    const float qw = d.qw[i], qz = d.qz[i];
+    if (packed == RK_FAR) {  // every road is beyond the radius: radiusFilter leaves nothing (src/knn.hpp:83-97, 156-157)
+        if (lane == 0) {
+            d.sel_hdr[(size_t)i * 2] = make_float4(ex, ey, qw, qz);
+            d.sel_hdr[(size_t)i * 2 + 1] = make_float4(__int_as_float(0), __int_as_float(r0), 0.f, 0.f);
+            d.cp_hdr[i] = make_float4(ex, ey, __int_as_float(0), 0.f);  // no checkpoints: nothing was replayed
+        }
+        return;
+    }
+    const int n = packed & 0xffff, nle = packed >> 16;
+    if (n < K) return;
+    __shared__ unsigned short s_don[4][K];
+    unsigned short *don = s_don[wave];
+    const unsigned int *hp = d.rk_heap + (size_t)i * GD_RANK_HEAP_DW;
+    const unsigned short *spc = d.rk_spc + (size_t)i * CAP;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+
+    // heap array -> road indices and in-radius flags (src/knn.hpp:88: length() <= radius; on ranks: fewer than `nle`
+    // candidates have a smaller key)
+    constexpr int NP = (K + 63) / 64;
+    int road[NP];
+    bool inr[NP];
+    unsigned long long fl[NP];
+    int m = 0;
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+        const int t = ps * 64 + lane, g = t + 1;
+        road[ps] = 0;
+        inr[ps] = false;
+        if (t < K) {
+            const unsigned int p2 = hp[g >> 1];
+            const unsigned int e = (g & 1) ? p2 >> 16 : p2 & 0xffffu;
+            const int less = (int)(e >> 5) - 1;
+            road[ps] = spc[less + (int)(e & 31u)];
+            inr[ps] = less < nle;
+        }
+        fl[ps] = __ballot(inr[ps]);
+        m += __popcll(fl[ps]);
+    }
+    // radiusFilter's swap-remove loop: with m in-radius elements, the out-of-radius slots below m (ascending) receive
+    // the in-radius elements of [m, K) in DESCENDING slot order; everything else below m stays
+    if (m < K) {
+        int above = 0;  // in-radius slots above the current pass
+#pragma unroll
+        for (int ps = NP - 1; ps >= 0; ps--) {
+            const int t = ps * 64 + lane;
+            if (t < K && t >= m && inr[ps]) don[above + __popcll(fl[ps] & ~lower & ~(1ull << lane))] = (unsigned short)road[ps];
+            above += __popcll(fl[ps]);
+        }
+        wave_sync();
+        int before = 0;  // slots below the current pass
+        int in_before = 0;
+#pragma unroll
+        for (int ps = 0; ps < NP; ps++) {
+            const int t = ps * 64 + lane;
+            if (t < m && !inr[ps]) {
+                const int h = (t - before) - __popcll(fl[ps] & lower) + (before - in_before);  // out-of-radius slots below t
+                road[ps] = don[h];
+            }
+            before += 64;
+            in_before += __popcll(fl[ps]);
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+        const int t = ps * 64 + lane;
+        if (t < K) d.sel_idx[(size_t)i * K + t] = (unsigned short)road[ps];
+    }
+    // the K-th distances at this selection's checkpoints: the exact key of the element whose rank was on top
+    // (a second copy is kept of the selection made at the start of an episode: a reset puts the agent back there)
+    const int ncp = 1 + (n - K) / TILE;
+    const bool at_start = d.steps[i] == (uint32_t)GD_EPISODE_LEN;
+    const size_t WA = (size_t)d.W * A_T;
+    if (lane < ncp) {
+        const unsigned int e = d.rk_cpe[(size_t)i * NCP + lane];
+        const int r = spc[(int)(e >> 5) - 1 + (int)(e & 31u)];
+        const float2 xy = d.road_xy[r0 + r];
+        const float t = ego_dist2(ex, ey, qw, -qz, xy.x, xy.y);
+        d.cp_T[(size_t)i * NCP + lane] = t;
+        if (at_start) {
+            d.cp_T[(WA + i) * NCP + lane] = t;
+            d.cp_road[(WA + i) * NCP + lane] = d.cp_road[(size_t)i * NCP + lane];
+        }
+    }
+    if (lane == 0) {
+        d.cp_hdr[i] = make_float4(ex, ey, __int_as_float(ncp), 0.f);
+        if (at_start) d.cp_hdr[WA + i] = make_float4(ex, ey, __int_as_float(ncp), 0.f);
+        d.sel_hdr[(size_t)i * 2] = make_float4(ex, ey, qw, qz);
+        d.sel_hdr[(size_t)i * 2 + 1] = make_float4(__int_as_float(m), __int_as_float(r0), 0.f, 0.f);
+    }
+}
+
+}  // namespace
+
+void launch_map_obs_rank(const DevSim &d, hipStream_t st) {
+    if (d.live_count == 0) return;
+    const dim3 gr(std::min(d.live_count, 256 * 8 * 4)), g4((d.live_count + 3) / 4), gw(d.W * (d.A / 64));  // rank: 8 waves per CU fit (LDS), four rounds of them
+    if (d.A == 64) {
+        hipLaunchKernelGGL((k_knn_scan<64>), gw, dim3(256), 0, st, d);
+        hipLaunchKernelGGL((k_knn_rank<64>), gr, dim3(64), 0, st, d);
+    } else {
+        hipLaunchKernelGGL((k_knn_scan<128>), gw, dim3(256), 0, st, d);
+        hipLaunchKernelGGL((k_knn_rank<128>), gr, dim3(64), 0, st, d);
+    }
+    hipLaunchKernelGGL(k_knn_bins, dim3(1), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_knn_order, dim3((d.live_count + 255) / 256), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_knn_replay, dim3((d.live_count + AWR - 1) / AWR), dim3(64), 0, st, d);
+    if (d.A == 64) hipLaunchKernelGGL((k_knn_finish<64>), g4, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((k_knn_finish<128>), g4, dim3(256), 0, st, d);
+}
+
+}  // namespace gd

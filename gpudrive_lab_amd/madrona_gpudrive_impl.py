@@ -397,6 +397,13 @@ class SimManager:
         _capi.check(self._L.gd_debug_get_state(self._h, out.ctypes.data))
         return out
 
+    def debug_road_path(self):
+        """[W, A] int32: > 0 rank replay (candidate count), -1 history replay on keys (fallback), 0 padding slot,
+        -2 rank replay not in use."""
+        out = np.zeros((self._W, self._A), np.int32)
+        _capi.check(self._L.gd_debug_road_path(self._h, out.ctypes.data))
+        return out
+
     def debug_set_state(self, st):
         st = np.ascontiguousarray(st, np.float32)
         assert st.shape == (self._W, self._A, 11)

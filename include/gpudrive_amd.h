@@ -227,6 +227,12 @@ int gd_kernel_timing_read(gd_sim *sim, int32_t kernel, double *total_ms, int64_t
  * {pos xyz, quat wxyz, vel xyz, collided}.  Device-to-host / host-to-device copies. */
 int gd_debug_get_state(gd_sim *sim, float *host_out);
 int gd_debug_set_state(gd_sim *sim, const float *host_in);
+/* Which kernel selected every agent slot's roads in the last reference-order selection: > 0 the rank replay
+ * (map_obs_rank.hip; the value is the agent's candidate count), -1 the history replay on keys (k_map_obs, the fallback:
+ * first selection after a map change, jumps, overflow; -1 because another agent of its group of 32 needed it, -10 no usable
+ * checkpoints or a world too small for the rank path, -11 more candidates than the buffer holds, -12 more than 32 equal keys), -3 no road of the world within reach of the radius (no rows),
+ * 0 no selection (padding slot), -2 the rank replay is not in use (set order, linear scan, GPUDRIVE_NO_RANK_REPLAY).  out: [W][A] int32 on the host. */
+int gd_debug_road_path(gd_sim *sim, int32_t *out);
 
 /* Host-only scene pipeline (no device): parse + build world `scene` exactly as gd_create would
  * and return the init-time rows, for CPU tests of the host logic.

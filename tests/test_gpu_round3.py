@@ -1,0 +1,348 @@
+"""GPU suite, round 3: the rank replay of the reference-order road selection (csrc/map_obs_rank.hip) against the history
+replay on keys it falls back to and against the oracle; oracle cross-checks at BASELINE.json's full sizes (first and last
+worlds of the batch, both workgroup generations, config 5); the road arrays' slack when a rebuild fits the old capacity;
+the set-order kernel's rule for ties at the K-th key.  Everything goes through `madrona_gpudrive` -> ctypes -> the C ABI."""
+import collections
+import json
+
+import numpy as np
+import pytest
+
+from gpudrive_lab_amd import synth
+from tests import parity as P
+from tests import ref_cases as RC
+from tests.conftest import SCENE_4, SCENE_407, TEST_JSON
+
+pytestmark = pytest.mark.gpu
+
+ALL_OBJECTS = dict(isStaticAgentControlled=1, initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
+BENCH = dict(observationRadius=50.0, collisionBehaviour=2, rewardType=1, distanceToGoalThreshold=2.0, dynamicsModel=0,
+             roadObservationAlgorithm=0, polylineReductionThreshold=0.0, **ALL_OBJECTS)
+CLASSIC = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=2, rewardType=1,
+               distanceToGoalThreshold=2.0, dynamicsModel=0, **ALL_OBJECTS)
+
+
+@pytest.fixture(scope="module")
+def bench_scenes(tmp_path_factory):
+    return synth.write_scenes(str(tmp_path_factory.mktemp("bench_scenes3")), list(range(8)))
+
+
+def _dup_scene(tmp_path):
+    """Three polylines twice: exactly equal keys among the candidates (tests/test_heap_pin.py builds the same scene)."""
+    sc = synth.make_scene(5, n_agents=12, n_polylines=10, pts_per_polyline=60)
+    sc["roads"] = sc["roads"] + [dict(r, id=100 + i) for i, r in enumerate(sc["roads"][:3])]
+    p = tmp_path / "dup.json"
+    p.write_text(json.dumps(sc))
+    return str(p)
+
+
+def _bits(t):
+    return RC.as_np(t).view(np.uint32)
+
+
+@pytest.mark.parametrize("which", ["bench", "waymo", "waymo_unreduced", "equal_keys"])
+def test_rank_replay_equals_history_replay_bit_for_bit(bench_scenes, tmp_path, monkeypatch, which):
+    """Two engines on the same scenes and actions, free running: one selects the roads with the rank replay, the other
+    with GPUDRIVE_NO_RANK_REPLAY=1 (k_map_obs alone, round 2's kernel).  agent_roadmap_tensor must be bit-identical at
+    every step -- through a reset of some worlds, a jump of a few agents (their bounds no longer hold) and agents that
+    finish and are parked at the padding position -- and the rank replay must actually have been taken."""
+    min_taken = 0.6
+    if which == "bench":
+        scenes, kw = bench_scenes[:3], BENCH
+    elif which == "waymo":
+        scenes, kw = [TEST_JSON, SCENE_407, SCENE_4], CLASSIC   # a few hundred roads per world: every road may be a candidate
+    elif which == "waymo_unreduced":
+        # thousands of roads with repeated points (equal keys) and more inserts than the candidate buffer holds for many
+        # agents: most groups take the fallback, all of it must still be bit-identical
+        scenes, kw, min_taken = [TEST_JSON, SCENE_407, SCENE_4], dict(CLASSIC, polylineReductionThreshold=0.0, observationRadius=60.0), 0.0
+    else:
+        scenes, kw = [_dup_scene(tmp_path), SCENE_407], dict(BENCH, observationRadius=200.0)
+    monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")   # small worlds too (by default k_map_obs keeps those)
+    fast = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    monkeypatch.setenv("GPUDRIVE_NO_RANK_REPLAY", "1")
+    slow = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    monkeypatch.delenv("GPUDRIVE_NO_RANK_REPLAY")
+    assert fast.stat(7) == 1 and slow.stat(7) == 0
+    assert (slow.debug_road_path() == -2).all()
+    W = len(scenes)
+    rng = np.random.default_rng(5)
+    taken = fell_back = 0
+    why = collections.Counter()
+    live = RC.as_np(fast.shape_tensor())[:, 0]
+    n_live = int(live.sum())
+
+    def same(tag):
+        a, b = _bits(fast.agent_roadmap_tensor()), _bits(slow.agent_roadmap_tensor())
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            raise AssertionError("%s: agent_roadmap differs at %d places, first %s" % (tag, len(bad), bad[0]))
+        for name in ("done_tensor", "info_tensor", "self_observation_tensor"):
+            assert np.array_equal(_bits(getattr(fast, name)()), _bits(getattr(slow, name)())), (tag, name)
+    same("t=0")
+    for k in range(24):
+        act = P.random_actions(rng, W, 64, 0)
+        RC.write_actions(fast, act)
+        RC.write_actions(slow, act)
+        fast.step()
+        slow.step()
+        same("step %d" % (k + 1))
+        path = fast.debug_road_path()
+        taken += int(((path > 0) | (path == -3)).sum())   # ranked, or parked out of reach of every road (no rows)
+        fell_back += int(((path == -1) | (path <= -10)).sum())
+        why.update(path[path <= -10].tolist())
+        if k == 8:  # some worlds go back to their start poses
+            fast.reset([0])
+            slow.reset([0])
+            same("reset")
+        if k == 14:  # a few agents jump 30 m: last step's bounds say nothing about where they are now
+            st = fast.debug_get_state()
+            st[:, :3, 0] += 30.0
+            fast.debug_set_state(st)
+            slow.debug_set_state(st)
+            fast.reset([])
+            slow.reset([])
+            same("jump")
+    print("rank replay taken for %d of %d agent-steps, fallback for %d (own reasons: %s)" % (taken, 24 * n_live, fell_back, dict(why)))
+    assert taken >= min_taken * 24 * n_live, "the rank replay was taken for only %d of %d agent-steps" % (taken, 24 * n_live)
+    fast.close()
+    slow.close()
+
+
+def test_rank_replay_lockstep_with_the_oracle_through_a_whole_episode(oracle_mod, bench_scenes):
+    """91 free-running steps on the bench scenes (agents finish and are parked along the way), then the reset: ints exact at
+    every step, every observation against the oracle under teacher forcing every 7th step."""
+    scenes = bench_scenes[:2]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **BENCH)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **BENCH)
+    P.lockstep(gpu, orc, 91, 0, seed=77, check_every=7)
+    path = gpu.debug_road_path()
+    assert (path[path != 0] != -1).all(), "no agent should need the fallback in the steady state"
+    gpu.reset([0, 1])
+    orc.reset([0, 1])
+    P.compare_fresh(gpu, orc)
+    assert (gpu.debug_road_path()[:, :64] > 0).all(), "a reset goes back to the episode's first checkpoints, not to the fallback"
+    P.lockstep(gpu, orc, 5, 0, seed=78)
+    gpu.close()
+
+
+# ---- BASELINE.json full sizes against the oracle ----
+def _tiled(n):
+    base = [TEST_JSON, SCENE_407, SCENE_4]
+    return [base[i % 3] for i in range(n)]
+
+
+class _Worlds:
+    """A few worlds of a big simulator seen as a small one (what tests/parity.py's comparisons take)."""
+
+    def __init__(self, sim, idx):
+        self._sim, self._idx = sim, list(idx)
+
+    def __getattr__(self, name):
+        if not name.endswith("_tensor"):
+            raise AttributeError(name)
+        full = getattr(self._sim, name)
+
+        def getter():
+            return RC.as_np(full())[self._idx]
+        return getter
+
+
+@pytest.mark.parametrize("W,collision,knn_order", [(1024, 2, 0), (4096, 0, 0), (1024, 2, 1)])
+def test_full_size_first_and_last_worlds_equal_the_oracle(oracle_mod, W, collision, knn_order):
+    """configs[1] / configs[2] at full size: the worlds are replicas of three scenes fed the same per-scene actions, so
+    three oracle worlds describe all of them.  Worlds 0-2 and the LAST three worlds of the batch are compared with the
+    oracle elementwise (ints exact, observations under teacher forcing), and every replica must equal its scene's first
+    world bit for bit -- which carries the comparison to all W worlds."""
+    import torch
+    kw = dict(CLASSIC, collisionBehaviour=collision)
+    gpu = P.make_gpu_sim(_tiled(W), max_agents=64, knn_order=knn_order, **kw)
+    orc = P.make_oracle_sim(oracle_mod, _tiled(3), max_agents=64, **kw)
+    rng = np.random.default_rng(3)
+    last = [W - 3, W - 2, W - 1]
+    last_scene = [w % 3 for w in last]
+    views = [(_Worlds(gpu, [0, 1, 2]), [0, 1, 2]), (_Worlds(gpu, last), last_scene)]
+    for step in range(13):
+        act3 = P.random_actions(rng, 3, 64, 0)
+        a = gpu.action_tensor().to_torch()
+        a.copy_(torch.as_tensor(act3).repeat((W + 2) // 3, 1, 1)[:W].to(a.device))
+        np.copyto(orc.action_tensor(), act3)
+        gpu.step()
+        orc.step()
+        for view, scene in views:
+            sub = _Worlds(orc, scene)
+            P.compare_ints(view, sub, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+        if step % 4 == 0:  # teacher forcing: the oracle's state into every replica, both recompute, observations compared
+            st = orc.get_state()
+            gpu.debug_set_state(np.tile(st, ((W + 2) // 3, 1, 1))[:W])
+            gpu.reset([])
+            orc.reset([])
+            for view, scene in views:
+                sub = _Worlds(orc, scene)
+                sub.W, sub.A = 3, 64
+                if knn_order == 0:
+                    P.compare_obs(view, sub)
+                else:
+                    P.compare_obs(view, sub, names=[n for n in P.OBS_TENSORS if n != "agent_roadmap_tensor"])
+                    P.compare_roadmap_as_set(view, sub)
+    for name in ["done_tensor", "info_tensor", "reward_tensor", "self_observation_tensor", "partner_observations_tensor",
+                 "agent_roadmap_tensor"]:
+        flat = getattr(gpu, name)().to_torch().reshape(W, -1)
+        for r in range(3):
+            grp = flat[r::3]
+            assert torch.equal(grp, grp[0:1].expand_as(grp)), "%s: replicas of scene %d diverged" % (name, r)
+    gpu.close()
+
+
+@pytest.mark.parametrize("knn_order", [0, 1], ids=["reference_order", "set_order"])
+def test_1024_bench_worlds_spread_over_both_generations_equal_the_oracle(oracle_mod, bench_scenes, knn_order):
+    """What bench.py times, at its size: 1024 worlds tiled from the 8 synthetic scenes, 14 steps (the reference-order
+    kernels re-sort their launch orders after every launch), the oracle on the 8 distinct scenes, 16 worlds spread over the
+    whole batch compared elementwise (set order: the road rows as a set)."""
+    import torch
+    W = 1024
+    scenes = [bench_scenes[i % 8] for i in range(W)]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, knn_order=knn_order, **BENCH)
+    orc = P.make_oracle_sim(oracle_mod, bench_scenes, max_agents=64, **BENCH)
+    picks = sorted(set(int(x) for x in np.linspace(0, W - 1, 16)))
+    view, sub_scene = _Worlds(gpu, picks), [w % 8 for w in picks]
+    rng = np.random.default_rng(9)
+    for step in range(14):
+        act8 = P.random_actions(rng, 8, 64, 0)
+        a = gpu.action_tensor().to_torch()
+        a.copy_(torch.as_tensor(act8).repeat(W // 8, 1, 1).to(a.device))
+        np.copyto(orc.action_tensor(), act8)
+        gpu.step()
+        orc.step()
+        sub = _Worlds(orc, sub_scene)
+        P.compare_ints(view, sub, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+        if step in (0, 5, 13):
+            gpu.debug_set_state(np.tile(orc.get_state(), (W // 8, 1, 1)))
+            gpu.reset([])
+            orc.reset([])
+            sub = _Worlds(orc, sub_scene)
+            sub.W, sub.A = len(picks), 64
+            if knn_order == 0:
+                P.compare_obs(view, sub)
+            else:
+                P.compare_obs(view, sub, names=[n for n in P.OBS_TENSORS if n != "agent_roadmap_tensor"])
+                P.compare_roadmap_as_set(view, sub)
+    if knn_order == 0:
+        path = gpu.debug_road_path()
+        assert (path > 0).mean() > 0.9, "the rank replay should carry the bench scenes"
+    gpu.close()
+
+
+def test_config5_lidar_at_1024_worlds(oracle_mod):
+    """configs[4] at its size: LiDAR rows of replicas identical, worlds 0-2 and the last three equal to the (modelled,
+    parity unpinned) oracle."""
+    import torch
+    W = 1024
+    kw = dict(CLASSIC, enableLidar=1)
+    gpu = P.make_gpu_sim(_tiled(W), max_agents=64, lidar_half_angle=float(np.pi), **kw)
+    orc = P.make_oracle_sim(oracle_mod, _tiled(3), max_agents=64, lidarHalfAngle=float(np.pi), **kw)
+    rng = np.random.default_rng(11)
+    last = [W - 3, W - 2, W - 1]
+    for step in range(4):
+        act3 = P.random_actions(rng, 3, 64, 0)
+        a = gpu.action_tensor().to_torch()
+        a.copy_(torch.as_tensor(act3).repeat((W + 2) // 3, 1, 1)[:W].to(a.device))
+        np.copyto(orc.action_tensor(), act3)
+        gpu.step()
+        orc.step()
+        gpu.debug_set_state(np.tile(orc.get_state(), ((W + 2) // 3, 1, 1))[:W])
+        gpu.reset([])
+        orc.reset([])
+    for idx in ([0, 1, 2], last):
+        sub = _Worlds(orc, [w % 3 for w in idx])
+        sub.W, sub.A = 3, 64
+        P.compare_lidar(_Worlds(gpu, idx), sub)
+    flat = gpu.lidar_tensor().to_torch().reshape(W, -1)
+    live = torch.as_tensor(np.arange(64)[None, :] < np.asarray(orc.shape_tensor())[:, 0:1])  # [3, 64]
+    per_agent = gpu.lidar_tensor().to_torch().reshape(W, 64, -1)
+    for r in range(3):
+        grp = per_agent[r::3][:, live[r]]
+        assert torch.equal(grp, grp[0:1].expand_as(grp)), "lidar rows of scene %d's replicas diverged" % r
+    assert flat.shape[0] == W
+    gpu.close()
+
+
+# ---- road arrays: readable slack behind the last world on every rebuild ----
+def test_rebuild_into_existing_capacity_keeps_the_pad(oracle_mod, tmp_path):
+    """k_map_obs prefetches up to 256 roads past a world's last one and the fused set-order write-out reads the first
+    record of a world without roads: the arrays must end in readable pad entries also when set_maps / deleteAgents
+    rebuild into the capacity of an earlier, larger road set, and when no world has a road at all."""
+    def scene(name, n_poly, pts, seed):
+        p = tmp_path / (name + ".json")
+        p.write_text(json.dumps(synth.make_scene(seed, n_agents=6, n_polylines=n_poly, pts_per_polyline=pts)))
+        return str(p)
+    big = scene("big", 8, 129, 1)        # 1024 roads
+    small = scene("small", 2, 65, 2)     # 128 roads: fits the old capacity with room to spare
+    edge = scene("edge", 8, 141, 3)      # 1120 roads: above `big`, inside its capacity + slack
+    none = scene("none", 0, 2, 4)        # no roads at all
+    kw = dict(BENCH, observationRadius=60.0)
+    for order in (0, 1):
+        gpu = P.make_gpu_sim([big, big], max_agents=64, knn_order=order, **kw)
+        orc = P.make_oracle_sim(oracle_mod, [big, big], max_agents=64, **kw)
+        for new in ([small, small], [edge, edge], [none, small], [none, none], [big, none]):
+            gpu.set_maps(new)
+            orc.set_maps(new)
+            if order == 0:
+                P.compare_fresh(gpu, orc)
+                P.lockstep(gpu, orc, 2, 0, seed=5)
+            else:
+                P.compare_ints(gpu, orc)
+                gpu.debug_set_state(orc.get_state())
+                gpu.reset([])
+                orc.reset([])
+                P.compare_roadmap_as_set(gpu, orc)
+        gpu.close()
+    zero = P.make_gpu_sim([none], max_agents=64, **kw)   # constructed without a single road
+    assert (RC.as_np(zero.agent_roadmap_tensor())[0, :6, :, 6] == 0).all()
+    zero.step()
+    zero.close()
+
+
+# ---- set order: ties at the K-th key ----
+def test_set_order_ties_at_the_kth_key(oracle_mod, tmp_path):
+    """Duplicated polylines put pairs of roads at exactly the same distance.  When such a pair straddles the K-th place the
+    reference keeps whichever the heap's history left in the array (src/knn.hpp:15-17, 138-151: strict `<`, so a later road
+    with an equal key never replaces an earlier one); the set-order kernel keeps the LOWEST ROAD INDEX among the tied roads.
+    Both rules pick the earlier road of a duplicated pair, so here the row sets are equal; the test also shows that the rows
+    of the two duplicates differ only in their id column, i.e. what a consumer would see if the rules ever disagreed."""
+    sc = synth.make_scene(5, n_agents=16, n_polylines=12, pts_per_polyline=60)
+    sc["roads"] = sc["roads"] + [dict(r, id=100 + i) for i, r in enumerate(sc["roads"][:6])]  # six polylines twice
+    p = tmp_path / "dup_set.json"
+    p.write_text(json.dumps(sc))
+    kw = dict(BENCH, observationRadius=300.0)   # the radius keeps everything: K binds for every agent
+    gpu = P.make_gpu_sim([str(p)], max_agents=64, knn_order=1, **kw)
+    orc = P.make_oracle_sim(oracle_mod, [str(p)], max_agents=64, **kw)
+    rng = np.random.default_rng(2)
+    straddles = 0
+    for step in range(6):
+        if step:
+            act = P.random_actions(rng, 1, 64, 0)
+            RC.write_actions(gpu, act)
+            np.copyto(orc.action_tensor(), act)
+            gpu.step()
+            orc.step()
+        gpu.debug_set_state(orc.get_state())
+        gpu.reset([])
+        orc.reset([])
+        P.compare_roadmap_as_set(gpu, orc)
+        rows = np.asarray(orc.agent_roadmap_tensor())[0]
+        n = int(np.asarray(orc.shape_tensor())[0, 0])
+        for a in range(n):
+            r = rows[a]
+            d2 = r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1]
+            kth = d2.max()
+            obs = orc.road_obs_of(0, a)
+            keys = obs[:, 0] * obs[:, 0] + obs[:, 1] * obs[:, 1]
+            tied = np.flatnonzero(keys == kth)
+            if len(tied) > 1:   # the K-th key is shared: exactly one of the tied roads is in the rows (the earliest)
+                straddles += 1
+                ids_in = set(r[d2 == kth][:, 7].tolist())
+                assert obs[tied[0], 7] in ids_in
+                twin = obs[tied]
+                assert np.array_equal(twin[0, :7], twin[1, :7]) and twin[0, 7] != twin[1, 7]
+    assert straddles > 0, "no agent had duplicated roads at its K-th distance: the scene does not exercise the tie rule"
+    gpu.close()
