@@ -179,8 +179,18 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         tracker = EpisodeTracker(sim)
 
     gc_ms = [0.0]
+    spin_steps = [0]
 
     def timed_stretch(k):
+        # Device spin-up: untimed steps for --spin-ms of wall clock right before the stretch.  After an idle period (the host
+        # builds the worlds for a second or more) this GPU delays the first work it is given by 10-90 ms in about one
+        # stretch out of twelve -- the kernels then run at full speed, the wall clock of a 20-step stretch triples; with
+        # the device kept busy for 200 ms first it did not happen in 60 stretches (tools/stall_probe2.py).
+        t_spin = time.perf_counter()
+        while 1e3 * (time.perf_counter() - t_spin) < args.spin_ms:
+            k = run_steps(sim, batches, all_worlds, 4, start=k, tracker=tracker)
+            spin_steps[0] += 4
+            torch.cuda.synchronize(device)
         if not KEEP_GC:
             gc.collect()
             gc.disable()
@@ -219,7 +229,7 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         agent_steps_per_s=total_live * args.steps / elapsed,
         padded_agent_steps_per_s=world * args.worlds * args.agents * args.steps / elapsed,
         timed_region=dict(graph_steps=graph_steps, plain_steps=plain_steps),
-        gc_ms_in_timed_stretches=gc_ms[0],
+        gc_ms_in_timed_stretches=gc_ms[0], spin_up_steps=spin_steps[0],
         worlds=args.worlds,
     )
     names = {0: "k_world_step", 1: "k_map_obs+k_map_rows"}
@@ -398,6 +408,9 @@ def main():
     ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop,synthetic_set,waymo_set,cfg3_set",
                     help="first = primary; synthetic | waymo | cfg3 | lidar (Waymo tiles + 360-degree LiDAR) | bev | rl_loop; "
                          "a _set suffix = the same scenes in set order (knn_order 1)")
+    ap.add_argument("--spin-ms", type=float, default=200.0,
+                    help="untimed steps for this many ms of wall clock before each timed stretch (device spin-up after the idle "
+                         "world build; 0 = none)")
     ap.add_argument("--headless", action="store_true",
                     help="also print the reference CLI's two lines (src/headless.cpp:145-155) for the primary workload on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -456,6 +469,8 @@ def main():
                             "steps), no instrumentation" % (primary["timed_region"]["graph_steps"], primary["timed_region"]["plain_steps"]),
             "ms_per_step_events": primary["ms_per_step_events"],
             "gc_ms_in_timed_stretches": primary["gc_ms_in_timed_stretches"],
+            "spin_up": "%g ms of untimed steps before each timed stretch (%d steps on the primary workload): after the idle world "
+                       "build the GPU delays its first work by 10-90 ms in about one stretch of twelve" % (args.spin_ms, primary["spin_up_steps"]),
             "python_gc": "left alone (GPUDRIVE_BENCH_KEEP_GC=1)" if KEEP_GC else "collected before and disabled during each timed stretch",
             "kernels_sum_us": primary["kernels_sum_us"],
             "roofline": primary["roofline"],
@@ -469,7 +484,7 @@ def main():
             "cpu_baseline": cpu,
             "other_workloads": [
                 {k: r[k] for k in ("workload", "knn_order", "worlds", "agent_steps_per_s", "padded_agent_steps_per_s", "ms_per_step",
-                                   "ms_per_step_events", "gc_ms_in_timed_stretches", "kernels_sum_us", "live_agents_per_rank", "road_entities_per_rank",
+                                   "ms_per_step_events", "gc_ms_in_timed_stretches", "spin_up_steps", "kernels_sum_us", "live_agents_per_rank", "road_entities_per_rank",
                                    "roofline", "kernels", "other_rooflines")}
                 for r in results[1:]],
             "init_seconds": primary["init_seconds"],

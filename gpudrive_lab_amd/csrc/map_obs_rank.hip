@@ -264,15 +264,20 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     const float kmax = d.radius_key_max;
     const float2 *rxy = d.road_xy + r0;
     int nle = 0;
+    float kmax_seen = 0.f;
 #pragma clang loop unroll_count(4)
     for (int p = lane; p < nin; p += 64) {
         const float2 xy = rxy[cidx[p]];
         const float key = ego_dist2(ex, ey, iw, iz, xy.x, xy.y);
         ckey[p] = key;
         nle += key <= kmax ? 1 : 0;
+        kmax_seen = fmaxf(kmax_seen, key);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nle += __shfl_xor(nle, off);
+    for (int off = 32; off > 0; off >>= 1) {
+        nle += __shfl_xor(nle, off);
+        kmax_seen = fmaxf(kmax_seen, __shfl_xor(kmax_seen, off));
+    }
     const float t_last = in.t_last;
     wave_sync();
     if (d.rk_dbg == 2) return;
@@ -286,9 +291,11 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     const float split = (t_last > 0.f && t_last < 1e30f) ? t_last * 1.5f : 1.f;
     const float lin_scale = (float)NLIN / split;
     const unsigned int split_bits = __float_as_uint(split);
+    // above `split` the buckets are uniform in the key's bit pattern (i.e. logarithmic) up to the largest candidate key
+    const float log_scale = (float)(NB - NLIN) / (float)(max(__float_as_uint(kmax_seen), split_bits + 1u) - split_bits + 1u);
     auto bucket_of = [&](float key) -> int {
         if (key < split) return min(NLIN - 1, max(0, (int)(key * lin_scale)));
-        return NLIN + (int)min((unsigned int)(NB - NLIN - 1), (__float_as_uint(key) - split_bits) >> 17);  // 64 buckets per octave
+        return NLIN + min(NB - NLIN - 1, (int)((float)(__float_as_uint(key) - split_bits) * log_scale));
     };
     constexpr int U = 4;
 #pragma clang loop unroll(disable)
@@ -366,9 +373,10 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             longest = max(longest, s1[u] - s0[u]);
 #pragma unroll
             for (int j = 0; j < M; j++) {
-                const bool in = s0[u] + j < s1[u];
-                less[u] += (in && mk[u][j] < k[u]) ? 1 : 0;
-                tie[u] += (in && mk[u][j] == k[u] && mp[u][j] < p) ? 1 : 0;
+                // bit operations, not &&: the short-circuit form compiles into a branch per term
+                const int in = s0[u] + j < s1[u] ? 1 : 0;
+                less[u] += in & (mk[u][j] < k[u] ? 1 : 0);
+                tie[u] += in & (mk[u][j] == k[u] ? 1 : 0) & (mp[u][j] < p ? 1 : 0);
             }
         }
         // larger buckets: all four candidates of the lane advance together (one LDS round trip per step, not four)
@@ -386,16 +394,16 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const bool in = s0[u] + j < s1[u];
-                less[u] += (in && mkk[u] < k[u]) ? 1 : 0;
-                tie[u] += (in && mkk[u] == k[u] && mpp[u] < p0 + 64 * u) ? 1 : 0;
+                const int in = s0[u] + j < s1[u] ? 1 : 0;
+                less[u] += in & (mkk[u] < k[u] ? 1 : 0);
+                tie[u] += in & (mkk[u] == k[u] ? 1 : 0) & (mpp[u] < p0 + 64 * u ? 1 : 0);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int p = p0 + 64 * u;
             if (p < nin) {
-                too_many_ties = too_many_ties || tie[u] > 31;
+                too_many_ties = too_many_ties | (tie[u] > 31);
                 cres[p] = (unsigned int)(((less[u] + 1) << 5) | (tie[u] & 31));
             }
         }

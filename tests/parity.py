@@ -16,6 +16,13 @@ OBS_ATOL = 1e-5
 # quaternion component (cosf/sinf of the half heading, device vs glibc) moves an egocentric
 # coordinate at 50 m by ~1.2e-5, so un-injected comparisons use a looser bound.
 FREE_OBS_ATOL = 5e-5
+# Integer-valued outputs (BASELINE.json north_star: bit-exact).  The BEV cell values and the LiDAR hit / type pattern follow
+# from float predicates on sin / cos / atan2 of per-entity headings; the device evaluates those in double and rounds once
+# (gd_math.hpp p_sin / p_cos / p_atan2), which equals glibc's float result except where glibc itself is not correctly
+# rounded.  The bounds below are the largest counts ever MEASURED on the test cases (printed by every run), not a tolerance
+# chosen in advance: 0 means bit-exact on every case.
+BEV_MAX_CELLS_OFF = 0
+LIDAR_MAX_RAYS_OFF = 0
 STATE_RTOL = 1e-6
 STATE_ATOL = 1e-5
 
@@ -206,7 +213,8 @@ def compare_lidar(gpu, orc, depth_atol=1e-4):
     hit_g, hit_o = g[..., 0] > 0, o[..., 0] > 0
     # a ray grazing a box corner may hit on one side only: allow a vanishing fraction
     mism = (hit_g != hit_o) | (g[..., 1] != o[..., 1])
-    assert mism.mean() <= 2e-4, "lidar hit/type pattern differs on %d of %d rays" % (mism.sum(), mism.size)
+    print("lidar: hit/type pattern differs on %d of %d rays" % (mism.sum(), mism.size))
+    assert mism.sum() <= LIDAR_MAX_RAYS_OFF, "lidar hit/type pattern differs on %d of %d rays" % (mism.sum(), mism.size)
     ok = ~mism
     assert np.allclose(g[ok][:, [0, 2, 3]], o[ok][:, [0, 2, 3]], atol=depth_atol, rtol=1e-5)
     return float(hit_o.mean())
@@ -219,5 +227,6 @@ def compare_bev(gpu, orc):
     g = as_np(gpu.bev_observation_tensor())[live]
     o = np.asarray(orc.bev_observation_tensor())[live]
     mism = g != o
-    assert mism.mean() <= 1e-4, "BEV differs on %d of %d cells" % (mism.sum(), mism.size)
+    print("bev: %d of %d cells differ" % (mism.sum(), mism.size))
+    assert mism.sum() <= BEV_MAX_CELLS_OFF, "BEV differs on %d of %d cells" % (mism.sum(), mism.size)
     return float((o != 0).mean())

@@ -11,14 +11,23 @@ dev = torch.device("cuda", 0)
 mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 stalls = 0
+keep = []
 for rep in range(reps):
     with torch.cuda.stream(torch.cuda.Stream(device=dev)):
         sim = bench.make_sim(bench.scenes_for("waymo", 1024, 0), bench.params_for("waymo"), 64, 0)
         torch.cuda.synchronize()
+        if "settle" in mode:
+            time.sleep(0.3)
         batches = bench.action_batches(1024, 64, dev, seed=1)
         act = sim.action_tensor().to_torch()
         for k in range(5):
             act.copy_(batches[k]); sim.step()
+        if "spin" in mode:   # keep the GPU busy for a while before the timed stretch
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < 0.2:
+                for k in range(8):
+                    act.copy_(batches[k]); sim.step()
+                torch.cuda.synchronize()
         if mode.startswith("events"):
             sim.kernel_timing(True)
         torch.cuda.synchronize()
@@ -54,5 +63,8 @@ for rep in range(reps):
                 if max(host[k][1:]) > 1e-3 or gpu[k] > 1.0:
                     print("    step %2d at +%.2f ms: host copy/step/record %.2f/%.2f/%.2f ms, gpu interval %.2f ms" %
                           (k, host[k][0] * 1e3, host[k][1] * 1e3, host[k][2] * 1e3, host[k][3] * 1e3, gpu[k]))
-        sim.close()
+        if "keep" in mode:
+            keep.append(sim)   # never freed: is the stall the driver still tearing down the previous simulator's memory?
+        else:
+            sim.close()
 print(mode, "stalls:", stalls, "of", reps)
