@@ -546,7 +546,17 @@ struct gd_sim {
         d.boxes = static_cast<const float4 *>(d_boxes);
         HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
         choose_set_schedule();
-        if (rk_alloc) {  // the rank replay runs when some world is large enough for it
+        if (rk_alloc) {
+            // Which worlds take the rank replay (neither path changes a result).  Measured at 64 agent slots (road
+            // observation, ms): 1024 worlds x 4096 roads 1.53 ranked / 1.84 on keys; 1024 Waymo tiles (346-873 roads) 0.58 /
+            // 0.47 -- there k_map_obs is one short generation of workgroups and the rank kernels' fixed costs do not pay;
+            // 4096 Waymo tiles 1.10 / 1.74 -- five generations of k_map_obs workgroups, where the ranked path's occupancy
+            // counts.  So: large worlds always, every world with at least K roads once k_map_obs would need more than three
+            // generations.  GPUDRIVE_RANK_MIN_ROADS pins the threshold.
+            int groups = 0;
+            for (int w = 0; w < W; w++) groups += (w_agents[w] + 31) / 32;
+            const char *pin = std::getenv("GPUDRIVE_RANK_MIN_ROADS");
+            d.rk_min_roads = pin ? std::atoi(pin) : (groups > 3 * 4 * cu_count ? GD_MAP_OBS_K : 1536);
             d.rk_on = 0;
             for (int w = 0; w < W; w++)
                 if (road_off[w + 1] - road_off[w] >= std::max(d.rk_min_roads, GD_MAP_OBS_K)) d.rk_on = 1;
@@ -857,7 +867,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         if (GD_MAP_OBS_AW == 32 && cfg->knn_order != GD_KNN_SET_ORDER && params->roadObservationAlgorithm == GD_ROADS_K_NEAREST &&
             std::getenv("GPUDRIVE_NO_RANK_REPLAY") == nullptr) {
             d.rk_on = 1;
-            d.rk_min_roads = std::getenv("GPUDRIVE_RANK_MIN_ROADS") ? std::atoi(std::getenv("GPUDRIVE_RANK_MIN_ROADS")) : 1536;
+            d.rk_min_roads = 1536;  // chosen with the worlds (rebuild_worlds)
             s->rk_alloc = true;
             d.rk_dbg = std::getenv("GPUDRIVE_RANK_DBG") ? std::atoi(std::getenv("GPUDRIVE_RANK_DBG")) : 0;
             d.rk_E = s->alloc_internal<uint16_t>(WA * GD_RANK_CAP + 64);  // the replay prefetches up to 24 entries past a row
