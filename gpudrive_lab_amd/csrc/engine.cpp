@@ -800,6 +800,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.A = A;
         d.p = *params;
         d.knn_order = cfg->knn_order;
+        d.step_dbg = std::getenv("GPUDRIVE_STEP_DBG") ? std::atoi(std::getenv("GPUDRIVE_STEP_DBG")) : 0;
         {
             (void)hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
             d.set_fused_rows = 0;  // chosen with the worlds (rebuild_worlds -> choose_set_schedule)

@@ -89,6 +89,7 @@ struct DevSim {
     const float2 *rcell_xy;        // the (x, y) of those roads, in the same (cell-sorted) order: one coalesced stream per grid row
     float4 *knn_prev;              // [W][A] {x, y, K-th key of the previous selection or +inf, 0}
     // reference-order road selection, rank replay (map_obs_rank.hip); rk_on = 0: k_map_obs alone selects
+    int step_dbg;  // diagnostic: k_world_step skips 1 = the road-box loop, 2 = the agent-agent loop, 3 = the partner rows (timing only)
     int rk_on;
     int rk_min_roads;  // worlds with fewer roads are selected by k_map_obs (the rank path's fixed costs do not pay there)
     int rk_dbg;  // diagnostic: k_knn_rank stops after phase n (timing only; results are wrong)
