@@ -100,7 +100,7 @@ struct DevSim {
     int32_t *rk_hist;      // [513] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path
     int32_t *rk_ticket;    // [W][A] bin << 20 | place inside the bin; -1 = not on the rank path this step
     int32_t *rk_order;     // [W][A] agents on the rank path, most candidates first
-    uint32_t *rk_words;    // [W][NCH][A] candidate bits of 32 roads (k_knn_scan -> k_knn_rank)
+    uint32_t *rk_words;    // [W][A][NCH] candidate bits of 32 roads, one row per agent (k_knn_scan -> k_knn_rank)
     float *rk_tl;          // [W][A] the last K-th key of the checkpoint set in use (scales the ranking buckets)
     const float4 *road_bbox;  // [W] (min x, min y, max x, max y) over the world's roads
     int32_t *rk_n;         // [W][A] candidates | in-radius candidates << 16; 0 = not on the rank path this step; 1 << 30 = too far from every road

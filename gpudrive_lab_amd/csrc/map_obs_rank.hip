@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "engine.hpp"
 #include "gd_math.hpp"
@@ -46,7 +47,7 @@ constexpr int NB = 1280;           // ranking buckets
 constexpr int NLIN = 768;          // of which linear in the key (up to 1.5 x the previous K-th key); the other 512 take
                                    // the eight octaves above that, 64 each: about one candidate per bucket on either side
 static_assert(K + (NCP - 1) * TILE >= CAP, "a checkpoint slot for every tile of candidates");
-static_assert(CAP % 64 == 0 && NB % 64 == 0 && CAP < 2047, "geometry; less + 1 fits 11 bits");
+static_assert(CAP % 64 == 0 && NB % 128 == 0 && CAP < 2047, "geometry; less + 1 fits 11 bits");
 constexpr int RK_FAR = 1 << 30;    // rk_n: no road of the world can be within the agent's radius
 
 __device__ __forceinline__ void wave_sync() {
@@ -154,30 +155,46 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
     const int ncp = s_ncp[lane];
     int q = -1;  // checkpoint in force for this lane
     const int nch = (R + 31) >> 5;
-    uint32_t *words = d.rk_words + (size_t)w * GD_RANK_NCH * A_T + a;
+    // A wave takes 16 consecutive chunks of the tile, 8 at a time: the agents' words of a batch are handed over agent-major
+    // (k_knn_rank reads an agent's words as one row) through an LDS transpose, 32 bytes per agent, wave and batch
+    constexpr int TB = 8;
+    __shared__ unsigned int s_tr[4][TB][65];
+    uint32_t *words = d.rk_words + ((size_t)w * A_T + a0) * GD_RANK_NCH;
     for (int tile = 0; tile < R; tile += SCAN_TILE) {
         __syncthreads();
         for (int r = tile + tid; r < min(R, tile + SCAN_TILE); r += 256) s_xy[r - tile] = d.road_xy[r0 + r];
         __syncthreads();
-        const int c_end = min(nch, (tile + SCAN_TILE) >> 5);
 #pragma clang loop unroll(disable)
-        for (int c = (tile >> 5) + wave; c < c_end; c += 4) {
-            const int base = c << 5;
-            while (q + 1 < ncp && (int)s_first[q + 1][lane] <= base) q++;
-            const float thr = q >= 0 ? s_thr[q][lane] : __builtin_inff();
-            const float2 *t = s_xy + (base - tile);
-            unsigned int wd = 0;
+        for (int c_first = (tile >> 5) + wave * 16; c_first < (tile >> 5) + wave * 16 + 16 && c_first < nch; c_first += TB) {
+#pragma clang loop unroll(disable)
+            for (int k = 0; k < TB; k++) {
+                const int c = c_first + k;
+                unsigned int wd = 0;
+                if (c < nch) {  // wave-uniform
+                    const int base = c << 5;
+                    while (q + 1 < ncp && (int)s_first[q + 1][lane] <= base) q++;
+                    const float thr = q >= 0 ? s_thr[q][lane] : __builtin_inff();
+                    const float2 *t = s_xy + (base - tile);
 #pragma unroll
-            for (int k = 31; k >= 0; k--) {
-                const float2 xy = t[k];  // the same address in every lane: a broadcast read
-                const float dx = xy.x - ex, dy = xy.y - ey;
-                const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                wd = __builtin_amdgcn_alignbit(wd, __float_as_uint(d2 - thr), 31);  // (wd << 1) | (d2 < thr)
+                    for (int j = 31; j >= 0; j--) {
+                        const float2 xy = t[j];  // the same address in every lane: a broadcast read
+                        const float dx = xy.x - ex, dy = xy.y - ey;
+                        const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                        wd = __builtin_amdgcn_alignbit(wd, __float_as_uint(d2 - thr), 31);  // (wd << 1) | (d2 < thr)
+                    }
+                    if (base < K) wd |= K - base >= 32 ? 0xffffffffu : (1u << (K - base)) - 1u;  // roads below K regardless
+                    const int left = R - base;
+                    if (left < 32) wd &= (1u << left) - 1u;
+                }
+                s_tr[wave][k][lane] = wd;
             }
-            if (base < K) wd |= K - base >= 32 ? 0xffffffffu : (1u << (K - base)) - 1u;  // roads below K regardless
-            const int left = R - base;
-            if (left < 32) wd &= (1u << left) - 1u;
-            if (ncp > 0) words[(size_t)c * A_T] = wd;
+            wave_sync();
+#pragma unroll
+            for (int it = 0; it < TB; it++) {
+                const int ag = it * 8 + (lane >> 3), k = lane & 7;
+                if (c_first + k < nch && s_ncp[ag] > 0) words[(size_t)ag * GD_RANK_NCH + c_first + k] = s_tr[wave][k][ag];
+            }
+            wave_sync();
         }
     }
 }
@@ -185,13 +202,21 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
 // ------------------------------------------------------------------------------------------------------------------
 // k_knn_rank: one wave per live agent.  Candidate words -> candidate list, exact keys, ranks.
 // ------------------------------------------------------------------------------------------------------------------
+// 10 KB of LDS per agent, so that sixteen waves fit a CU: the kernel is a chain of LDS and memory round trips, and with two
+// waves per SIMD (20 KB) it waited 46 % of its cycles (profiles/r03: SQ_WAIT_ANY).  A lane keeps its up to 20 candidates
+// (positions lane, lane + 64, ...) in registers through all passes; LDS holds only what lanes exchange.
 struct RankLds {
-    float ckey[CAP];             // candidate keys, road order; then every candidate's rank
-    unsigned short cidx[CAP];    // candidate road indices, road order
-    float skey[CAP];             // the keys again, bucket order; then sorted slot -> road index
-    unsigned short spos[CAP];    // bucket order -> candidate position
-    int cnt[NB];                 // bucket counters, then cursors: after the scatter cnt[b] is the END of bucket b
+    union {
+        unsigned short cidx[CAP];       // candidate road indices in road order, while the word expansion hands them to their lanes
+        struct {
+            float skey[CAP];            // the keys in bucket order
+            unsigned short spos[CAP];   // bucket order -> candidate position
+        } s;
+        unsigned short spc[CAP];        // at the end: sorted slot -> road index
+    };
+    unsigned int cnt2[NB / 2];          // bucket counters, two u16 per word; then cursors: after the scatter the END of each bucket
 };
+static_assert(sizeof(RankLds) <= 10240, "sixteen waves per CU");
 
 // What the ranking of one agent reads from global memory before it can start, fetched while the previous agent of the
 // wave is being ranked (the fetches are a chain of dependent loads, several microseconds end to end).
@@ -206,18 +231,18 @@ __device__ __forceinline__ RankIn rank_fetch(const DevSim &d, int li, int lane) 
     RankIn in;
     in.i = li < d.live_count ? d.live_list[li] : 0;
     in.state = li < d.live_count ? d.rk_n[in.i] : 0;
-    const int w = in.i / A_T, a = in.i - w * A_T;
+    const int w = in.i / A_T;
     in.r0 = d.road_off[w];
     in.R = d.road_off[w + 1] - in.r0;
     in.ex = d.px[in.i]; in.ey = d.py[in.i];
     in.iw = d.qw[in.i]; in.iz = -d.qz[in.i];  // the INVERSE rotation
     in.t_last = d.rk_tl[in.i];
     const int nch = (in.R + 31) >> 5;
-    const uint32_t *words = d.rk_words + (size_t)w * GD_RANK_NCH * A_T + a;
+    const uint32_t *words = d.rk_words + (size_t)in.i * GD_RANK_NCH;  // agent-major: one coalesced read
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
         const int c = k * 64 + lane;
-        in.wd[k] = (in.state == 1 && c < nch) ? words[(size_t)c * A_T] : 0u;
+        in.wd[k] = (in.state == 1 && c < nch) ? words[c] : 0u;
     }
     return in;
 }
@@ -227,9 +252,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     if (in.state != 1) return;  // fallback or too far from every road (k_knn_scan)
     const int i = in.i, r0 = in.r0, R = in.R;
     const int group = i / 32;  // 32 consecutive agent slots of a world: the fallback unit (a workgroup of k_map_obs)
-    float *ckey = L.ckey, *skey = L.skey;
-    unsigned short *cidx = L.cidx, *spos = L.spos;
-    int *cnt = L.cnt;
+    constexpr int NG = CAP / 64;  // candidates per lane
 
     // ---- candidate words -> road indices in ascending order ----
     const int nch = (R + 31) >> 5;
@@ -245,7 +268,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         nin += __builtin_amdgcn_readlane(incl, 63);
         if (nin > CAP) break;  // wave-uniform
         while (wd) {
-            cidx[pos++] = (unsigned short)((c << 5) + __ffs(wd) - 1);
+            L.cidx[pos++] = (unsigned short)((c << 5) + __ffs(wd) - 1);
             wd &= wd - 1u;
         }
     }
@@ -259,19 +282,27 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     }
     wave_sync();
     if (d.rk_dbg == 1) return;
-    // ---- exact keys (gd_math.hpp ego_dist2: the reference's arithmetic) ----
+    int ci[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) ci[g] = g * 64 + lane < nin ? (int)L.cidx[g * 64 + lane] : 0;
+    wave_sync();  // the index buffer becomes the sorted arrays
+    // ---- exact keys (gd_math.hpp ego_dist2: the reference's arithmetic); every gather of the lane is in flight at once ----
     const float ex = in.ex, ey = in.ey, iw = in.iw, iz = in.iz;
     const float kmax = d.radius_key_max;
     const float2 *rxy = d.road_xy + r0;
+    float key[NG];
     int nle = 0;
     float kmax_seen = 0.f;
-#pragma clang loop unroll_count(4)
-    for (int p = lane; p < nin; p += 64) {
-        const float2 xy = rxy[cidx[p]];
-        const float key = ego_dist2(ex, ey, iw, iz, xy.x, xy.y);
-        ckey[p] = key;
-        nle += key <= kmax ? 1 : 0;
-        kmax_seen = fmaxf(kmax_seen, key);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        key[g] = 0.f;
+        if (g * 64 < nin) {  // wave-uniform
+            const float2 xy = rxy[ci[g]];
+            key[g] = ego_dist2(ex, ey, iw, iz, xy.x, xy.y);
+            const bool on = g * 64 + lane < nin;
+            nle += (on && key[g] <= kmax) ? 1 : 0;
+            kmax_seen = fmaxf(kmax_seen, on ? key[g] : 0.f);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -279,107 +310,96 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         kmax_seen = fmaxf(kmax_seen, __shfl_xor(kmax_seen, off));
     }
     const float t_last = in.t_last;
-    wave_sync();
     if (d.rk_dbg == 2) return;
 
     // ---- ranks.  Counting sort into NB buckets (a monotone function of the key: linear up to 1.5 x the previous
-    // K-th key, where most candidates lie, logarithmic beyond), then the exact order inside each bucket.  Every pass
-    // takes four candidates per lane at a time: the passes are chains of LDS round trips, and four independent chains
-    // hide each other's latency ----
-    for (int b = lane; b < NB; b += 64) cnt[b] = 0;
+    // K-th key, where most candidates lie, logarithmic beyond), then the exact order inside each bucket ----
+    for (int b = lane; b < NB / 2; b += 64) L.cnt2[b] = 0u;
     wave_sync();
     const float split = (t_last > 0.f && t_last < 1e30f) ? t_last * 1.5f : 1.f;
     const float lin_scale = (float)NLIN / split;
     const unsigned int split_bits = __float_as_uint(split);
     // above `split` the buckets are uniform in the key's bit pattern (i.e. logarithmic) up to the largest candidate key
     const float log_scale = (float)(NB - NLIN) / (float)(max(__float_as_uint(kmax_seen), split_bits + 1u) - split_bits + 1u);
-    auto bucket_of = [&](float key) -> int {
-        if (key < split) return min(NLIN - 1, max(0, (int)(key * lin_scale)));
-        return NLIN + min(NB - NLIN - 1, (int)((float)(__float_as_uint(key) - split_bits) * log_scale));
+    auto bucket_of = [&](float k) -> int {
+        if (k < split) return min(NLIN - 1, max(0, (int)(k * lin_scale)));
+        return NLIN + min(NB - NLIN - 1, (int)((float)(__float_as_uint(k) - split_bits) * log_scale));
     };
-    constexpr int U = 4;
-#pragma clang loop unroll(disable)
-    for (int p0 = lane; p0 < nin; p0 += 64 * U) {
-        float k[U];
+    // (the bucket rides in the upper half of the road-index register: registers decide how many waves a SIMD holds)
 #pragma unroll
-        for (int u = 0; u < U; u++) k[u] = p0 + 64 * u < nin ? ckey[p0 + 64 * u] : 0.f;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (p0 + 64 * u < nin) atomicAdd(&cnt[bucket_of(k[u])], 1);
+    for (int g = 0; g < NG; g++) {
+        const int b = bucket_of(key[g]);
+        ci[g] |= b << 16;
+        if (g * 64 + lane < nin) atomicAdd(&L.cnt2[b >> 1], 1u << ((b & 1) * 16));
     }
     wave_sync();
     {
-        // exclusive prefix over the buckets: lane l owns buckets l * (NB / 64) ..
-        constexpr int BPL = NB / 64;
-        int own[BPL], sum = 0;
+        // exclusive prefix over the buckets: lane l owns buckets l * (NB / 64) .. (an even number of them: whole words)
+        constexpr int WPB = NB / 64 / 2;
+        static_assert(WPB * 128 == NB, "whole counter words per lane");
+        unsigned int own[WPB];
+        int sum = 0;
 #pragma unroll
-        for (int k = 0; k < BPL; k++) { own[k] = cnt[lane * BPL + k]; sum += own[k]; }
+        for (int k = 0; k < WPB; k++) { own[k] = L.cnt2[lane * WPB + k]; sum += (int)(own[k] & 0xffffu) + (int)(own[k] >> 16); }
         int run = wave_incl_scan(sum) - sum;
 #pragma unroll
-        for (int k = 0; k < BPL; k++) { cnt[lane * BPL + k] = run; run += own[k]; }
+        for (int k = 0; k < WPB; k++) {
+            const int lo = run, hi = run + (int)(own[k] & 0xffffu);
+            run = hi + (int)(own[k] >> 16);
+            L.cnt2[lane * WPB + k] = (unsigned int)lo | (unsigned int)hi << 16;
+        }
     }
     wave_sync();
     if (d.rk_dbg == 3) return;
-#pragma clang loop unroll(disable)
-    for (int p0 = lane; p0 < nin; p0 += 64 * U) {
-        float k[U];
-        int sl[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) k[u] = p0 + 64 * u < nin ? ckey[p0 + 64 * u] : 0.f;
-#pragma unroll
-        for (int u = 0; u < U; u++) sl[u] = p0 + 64 * u < nin ? atomicAdd(&cnt[bucket_of(k[u])], 1) : 0;  // any order inside the bucket
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (p0 + 64 * u < nin) {
-                skey[sl[u]] = k[u];
-                spos[sl[u]] = (unsigned short)(p0 + 64 * u);
-            }
+    for (int g = 0; g < NG; g++) {
+        if (g * 64 + lane < nin) {
+            const int b = ci[g] >> 16, sh = (b & 1) * 16;
+            const int sl = (int)((atomicAdd(&L.cnt2[b >> 1], 1u << sh) >> sh) & 0xffffu);  // any order inside the bucket
+            L.s.skey[sl] = key[g];
+            L.s.spos[sl] = (unsigned short)(g * 64 + lane);
         }
     }
     wave_sync();
     if (d.rk_dbg == 4) return;
-    bool too_many_ties = false;
-    unsigned int *cres = reinterpret_cast<unsigned int *>(ckey);  // a candidate's result replaces its key
-#pragma clang loop unroll(disable)
-    for (int p0 = lane; p0 < nin; p0 += 64 * U) {
-        float k[U];
-        int s0[U], s1[U];
+    const unsigned short *cur16 = reinterpret_cast<const unsigned short *>(L.cnt2);  // cursor of bucket b = its END
+    int too_many_ties = 0, any_tie = 0;
+    unsigned int e[NG];
+    constexpr int U = 4, M = 4;
 #pragma unroll
-        for (int u = 0; u < U; u++) k[u] = p0 + 64 * u < nin ? ckey[p0 + 64 * u] : 0.f;
+    for (int g0 = 0; g0 < NG; g0 += U) {
+        if (g0 * 64 >= nin) break;  // wave-uniform
+        int s0[U], s1[U], less[U], tie[U], longest = 0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int b = bucket_of(k[u]);
-            s0[u] = b ? cnt[b - 1] : 0;
-            s1[u] = p0 + 64 * u < nin ? cnt[b] : s0[u];
+            const int b = ci[g0 + u] >> 16;
+            s0[u] = b ? (int)cur16[b - 1] : 0;
+            s1[u] = (g0 + u) * 64 + lane < nin ? (int)cur16[b] : s0[u];
         }
         // the first four members of every bucket at once (most buckets hold fewer), the rest in a loop
-        constexpr int M = 4;
-        float mk[U][M];
-        int mp[U][M];
 #pragma unroll
-        for (int u = 0; u < U; u++)
+        for (int u = 0; u < U; u++) {
+            const int p = (g0 + u) * 64 + lane;
+            float mk[M];
+            int mp[M];
 #pragma unroll
             for (int j = 0; j < M; j++) {
                 const int m = min(s0[u] + j, CAP - 1);
-                mk[u][j] = skey[m];
-                mp[u][j] = spos[m];
+                mk[j] = L.s.skey[m];
+                mp[j] = L.s.spos[m];
             }
-        int less[U], tie[U], longest = 0;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int p = p0 + 64 * u;
             less[u] = s0[u];
             tie[u] = 0;
             longest = max(longest, s1[u] - s0[u]);
 #pragma unroll
             for (int j = 0; j < M; j++) {
                 // bit operations, not &&: the short-circuit form compiles into a branch per term
-                const int in = s0[u] + j < s1[u] ? 1 : 0;
-                less[u] += in & (mk[u][j] < k[u] ? 1 : 0);
-                tie[u] += in & (mk[u][j] == k[u] ? 1 : 0) & (mp[u][j] < p ? 1 : 0);
+                const int inb = s0[u] + j < s1[u] ? 1 : 0;
+                less[u] += inb & (mk[j] < key[g0 + u] ? 1 : 0);
+                tie[u] += inb & (mk[j] == key[g0 + u] ? 1 : 0) & (mp[j] < p ? 1 : 0);
             }
         }
-        // larger buckets: all four candidates of the lane advance together (one LDS round trip per step, not four)
+        // larger buckets: the four candidates advance together (one LDS round trip per step, not four)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off));
         if (d.rk_dbg == 7) longest = 0;
@@ -389,28 +409,26 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int m = min(s0[u] + j, CAP - 1);
-                mkk[u] = skey[m];
-                mpp[u] = spos[m];
+                mkk[u] = L.s.skey[m];
+                mpp[u] = L.s.spos[m];
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int in = s0[u] + j < s1[u] ? 1 : 0;
-                less[u] += in & (mkk[u] < k[u] ? 1 : 0);
-                tie[u] += in & (mkk[u] == k[u] ? 1 : 0) & (mpp[u] < p0 + 64 * u ? 1 : 0);
+                const int inb = s0[u] + j < s1[u] ? 1 : 0;
+                less[u] += inb & (mkk[u] < key[g0 + u] ? 1 : 0);
+                tie[u] += inb & (mkk[u] == key[g0 + u] ? 1 : 0) & (mpp[u] < (g0 + u) * 64 + lane ? 1 : 0);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int p = p0 + 64 * u;
-            if (p < nin) {
-                too_many_ties = too_many_ties | (tie[u] > 31);
-                cres[p] = (unsigned int)(((less[u] + 1) << 5) | (tie[u] & 31));
-            }
+            too_many_ties |= ((g0 + u) * 64 + lane < nin && tie[u] > 31) ? 1 : 0;
+            any_tie |= (g0 + u) * 64 + lane < nin ? tie[u] : 0;
+            e[g0 + u] = (unsigned int)(((less[u] + 1) << 5) | (tie[u] & 31));
         }
     }
-    wave_sync();
+    wave_sync();  // every read of the sorted arrays is done: their space becomes the slot -> road table
     if (d.rk_dbg == 5) return;
-    if (__ballot(too_many_ties) != 0ull) {
+    if (__ballot(too_many_ties != 0) != 0ull) {
         if (lane == 0) {
             d.rk_n[i] = 0;
             d.rk_ticket[i] = -4;  // more than 32 candidates with one key
@@ -418,27 +436,28 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
         return;
     }
-    unsigned short *spc = reinterpret_cast<unsigned short *>(skey);  // sorted slot -> road index; the bucket-order keys are done with
-#pragma clang loop unroll_count(4)
-    for (int p = lane; p < nin; p += 64) {
-        const unsigned int e = cres[p];
-        d.rk_E[(size_t)i * CAP + p] = (unsigned short)e;
-        spc[(int)(e >> 5) - 1 + (int)(e & 31u)] = cidx[p];
-    }
-    wave_sync();
-    for (int s = lane; s < nin; s += 64) d.rk_spc[(size_t)i * CAP + s] = spc[s];
     // where this selection's checkpoints start to apply (their K-th distances are filled in by k_knn_finish):
     // checkpoint 0 is the heap of the first K roads (road indices below K are candidates regardless), checkpoint q
     // the heap after candidate K + 32 q - 1, which holds for every road behind that candidate; rounded up to whole
     // 64-road pieces of the scan
-    const int ncp_new = 1 + (nin - K) / TILE;
-    if (lane < ncp_new) {
-        int first = (K / 64) * 64;
-        if (lane > 0) first = ((int)cidx[K + TILE * lane - 1] + 1 + 63) & ~63;
-        d.cp_road[(size_t)i * NCP + lane] = (unsigned short)min(first, 65535);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int p = g * 64 + lane;
+        if (p < nin) {
+            d.rk_E[(size_t)i * CAP + p] = (unsigned short)e[g];
+            const int road = ci[g] & 0xffff;
+            L.spc[(int)(e[g] >> 5) - 1 + (int)(e[g] & 31u)] = (unsigned short)road;
+            const int t = p - K + 1;  // candidates beyond the first K up to and including this one
+            if (t > 0 && (t & (TILE - 1)) == 0)
+                d.cp_road[(size_t)i * NCP + t / TILE] = (unsigned short)min(65535, (road + 1 + 63) & ~63);
+        }
     }
+    if (lane == 0) d.cp_road[(size_t)i * NCP] = (unsigned short)((K / 64) * 64);
+    wave_sync();
+    for (int s = lane; s < nin; s += 64) d.rk_spc[(size_t)i * CAP + s] = L.spc[s];
+    const bool has_tie = __ballot(any_tie != 0) != 0ull;  // the replay then compares ranks without their tie field
     if (lane == 0) {
-        d.rk_n[i] = nin | (nle << 16);
+        d.rk_n[i] = nin | (nle << 16) | (has_tie ? 1 << 28 : 0);
         const int bin = 255 - min(255, (nin - K) / 5);  // longest first
         d.rk_ticket[i] = bin << 20 | atomicAdd(&d.rk_hist[bin], 1);
     }
@@ -447,7 +466,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
 // A wave ranks several agents in turn: tens of thousands of one-agent workgroups cost more in workgroup launches (each is
 // handed its 20 KB of LDS first) than in work.
 template <int A_T>
-__global__ __launch_bounds__(64) void k_knn_rank(DevSim d) {
+__global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 registers: four waves per SIMD, like the LDS
     if (d.gate_any && *d.any_reset == 0) return;
     __shared__ RankLds L;
     RankIn cur = rank_fetch<A_T>(d, blockIdx.x, threadIdx.x);
@@ -512,10 +531,12 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
     constexpr int NPAIR = 128;  // pairs 0..K/2 hold the heap; K/2 + 1 .. 127 stay 0: the "children" of slots beyond the heap
     __shared__ unsigned int s_pair[NPAIR * AWR];
     const RankHeap H{s_pair + (lane % AWR)};
-    int i = 0, n = 0;
+    int i = 0, n = 0, has_tie = 0;
     if (lane < AWR && li < d.rk_hist[512]) {
         i = d.rk_order[li];
-        n = d.rk_n[i] & 0xffff;
+        const int packed = d.rk_n[i];
+        n = packed & 0xffff;
+        has_tie = (packed >> 28) & 1;
         if (d.rk_fallback[i / 32] != 0) n = 0;  // the whole group is selected by k_map_obs
     }
     const bool on = n >= K;  // never true for the upper lanes, which share LDS columns with the lower ones
@@ -583,93 +604,125 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
     const uint4 *blocks = reinterpret_cast<const uint4 *>(E + K);  // K * 2 bytes: 16-byte aligned
     uint4 cur = on ? blocks[0] : make_uint4(0u, 0u, 0u, 0u);
     uint4 nxt = on ? blocks[1] : make_uint4(0u, 0u, 0u, 0u);
+    // Two copies of the loop.  When none of the wave's agents has two candidates with one key (k_knn_rank reports it), every
+    // rank's tie field is 0, a plain integer compare IS the key compare, "the larger child" is a max and the values along
+    // the pop's path and the push's chain are medians of three (the moved children are non-increasing down the path, the
+    // chain towards the leaf): about a third fewer instructions per insert.  The other copy compares ranks without their
+    // tie field and selects.
+    auto replay = [&](auto ties_tag) {
+        constexpr bool TIES = decltype(ties_tag)::value;
+        auto lt = [](unsigned int a, unsigned int b) -> bool { return TIES ? rank_lt(a, b) : a < b; };
+        auto larger = [&](unsigned int kl, unsigned int kr, bool &right) -> unsigned int {
+            right = !lt(kr, kl);  // the right child unless it is smaller (src/binary_heap.hpp __adjust_heap)
+            return TIES ? (right ? kr : kl) : max(kl, kr);
+        };
+        auto med3 = [](unsigned int a, unsigned int b, unsigned int c) -> unsigned int {
+            return max(min(a, b), min(max(a, b), c));  // the backend folds this into v_med3_u32
+        };
 #pragma clang loop unroll(disable)
-    for (int p = K; p < nmax; p++) {
-        const int t = p - K;
-        const unsigned int y = cur.x & 0xffffu;
-        cur.x = (cur.x >> 16) | (cur.y << 16);
-        cur.y = (cur.y >> 16) | (cur.z << 16);
-        cur.z = (cur.z >> 16) | (cur.w << 16);
-        cur.w = cur.w >> 16;
-        if ((t & 7) == 7) {
-            cur = nxt;
-            if (on) nxt = blocks[(t >> 3) + 2];  // may run past this agent's candidates: the array ends in slack
+        for (int p = K; p < nmax; p++) {
+            const int t = p - K;
+            const unsigned int y = cur.x & 0xffffu;
+            cur.x = (cur.x >> 16) | (cur.y << 16);
+            cur.y = (cur.y >> 16) | (cur.z << 16);
+            cur.z = (cur.z >> 16) | (cur.w << 16);
+            cur.w = cur.w >> 16;
+            if ((t & 7) == 7) {
+                cur = nxt;
+                if (on) nxt = blocks[(t >> 3) + 2];  // may run past this agent's candidates: the array ends in slack
+            }
+            if (p < n && lt(y, r[1])) {
+                // pop_heap: the hole goes from the root to the bottom of the (K - 1)-element heap along the larger child.
+                // Levels 0 and 1 are decided in registers (slots 1..7 live there during the replay); below that two levels
+                // per LDS round trip: a node's children pair and both grandchildren pairs are fetched together (pairs beyond
+                // the heap hold 0, which loses every comparison).  The ancestors of slot K that the push will meet are
+                // requested now as well and patched where the pop's path went through them.
+                int g[8];
+                unsigned int ck[7];
+                bool right0, right1;
+                ck[0] = larger(r[2], r[3], right0);
+                const unsigned int hl = right0 ? r[6] : r[4], hr = right0 ? r[7] : r[5];
+                ck[1] = larger(hl, hr, right1);
+                g[0] = 1;
+                g[1] = 2 + (right0 ? 1 : 0);
+                g[2] = 2 * g[1] + (right1 ? 1 : 0);
+                const unsigned int q12 = H.get(12), q25 = H.get(25), q50 = H.get(50), q100 = H.get(100);
+#pragma unroll
+                for (int l = 2; l < 6; l += 2) {
+                    const unsigned int pc = H.pair(g[l]), pl = H.pair(2 * g[l]), pr2 = H.pair(2 * g[l] + 1);
+                    bool right, right2;
+                    ck[l] = larger(pc & 0xffffu, pc >> 16, right);
+                    g[l + 1] = 2 * g[l] + (right ? 1 : 0);
+                    const unsigned int pg = right ? pr2 : pl;
+                    ck[l + 1] = larger(pg & 0xffffu, pg >> 16, right2);
+                    g[l + 2] = 2 * g[l + 1] + (right2 ? 1 : 0);
+                }
+                {
+                    const unsigned int pc = H.pair(g[6]);
+                    bool right;
+                    ck[6] = larger(pc & 0xffffu, pc >> 16, right);
+                    g[7] = 2 * g[6] + (right ? 1 : 0);
+                }
+                // the old last element climbs back from the leaf hole past every moved child that is smaller; the moved
+                // children are non-increasing down the path, so "it passes level l" is monotone in l and the value that
+                // ends up on level l is the median of (child moved from l, child moved from l + 1 ... ) -- see above
+                unsigned int v[8];
+                if (TIES) {
+                    bool c[7];
+#pragma unroll
+                    for (int l = 0; l < 7; l++) c[l] = lt(ck[l], last);
+#pragma unroll
+                    for (int l = 0; l < 8; l++) {
+                        if (l == 0) v[l] = c[0] ? last : ck[0];
+                        else if (l == 7) v[l] = c[6] ? ck[6] : last;
+                        else v[l] = c[l - 1] ? ck[l - 1] : (c[l] ? last : ck[l]);
+                    }
+                } else {
+                    v[0] = max(ck[0], last);
+#pragma unroll
+                    for (int l = 1; l < 7; l++) v[l] = med3(ck[l - 1], ck[l], last);
+                    v[7] = min(ck[6], last);
+                }
+                r[1] = v[0];
+                r[2] = right0 ? r[2] : v[1];
+                r[3] = right0 ? v[1] : r[3];
+#pragma unroll
+                for (int j = 4; j < 8; j++) r[j] = g[2] == j ? v[2] : r[j];
+#pragma unroll
+                for (int l = 3; l < 8; l++)
+                    if (l < 6 || g[l] < K) H.set(g[l], v[l]);  // levels 3..5 are always inside the heap
+                // push_heap: the new element climbs from slot K along 100, 50, 25, 12, 6, 3, 1
+                static_assert(K == 200, "ancestor chain of slot K");
+                const unsigned int qv[7] = {r[1], r[3], r[6], g[3] == 12 ? v[3] : q12, g[4] == 25 ? v[4] : q25,
+                                            g[5] == 50 ? v[5] : q50, g[6] == 100 ? v[6] : q100};
+                constexpr int chain[7] = {1, 3, 6, 12, 25, 50, 100};
+                if (TIES) {
+                    bool pp[7];
+#pragma unroll
+                    for (int u = 0; u < 7; u++) pp[u] = lt(qv[u], y);
+                    r[1] = pp[0] ? y : r[1];
+                    r[3] = pp[1] ? (pp[0] ? qv[0] : y) : r[3];
+                    r[6] = pp[2] ? (pp[1] ? qv[1] : y) : r[6];
+#pragma unroll
+                    for (int u = 3; u < 7; u++)
+                        if (pp[u]) H.set(chain[u], pp[u - 1] ? qv[u - 1] : y);
+                    last = pp[6] ? qv[6] : y;
+                } else {
+                    // chain position u receives its parent's value if that is below y, y if only its own is, and keeps its
+                    // own otherwise: the median of (parent, own, y), the chain being non-increasing towards the leaf
+                    r[1] = max(qv[0], y);
+                    r[3] = med3(qv[0], qv[1], y);
+                    r[6] = med3(qv[1], qv[2], y);
+#pragma unroll
+                    for (int u = 3; u < 7; u++) H.set(chain[u], med3(qv[u - 1], qv[u], y));
+                    last = min(qv[6], y);
+                }
+            }
+            if (((t + 1) & (TILE - 1)) == 0 && p < n) cpe[(t + 1) / TILE] = (unsigned short)r[1];
         }
-        if (p < n && rank_lt(y, r[1])) {
-            // pop_heap: the hole goes from the root to the bottom of the (K - 1)-element heap along the larger child.
-            // Levels 0 and 1 are decided in registers (slots 1..7 live there during the replay); below that two levels
-            // per LDS round trip: a node's children pair and both grandchildren pairs are fetched together (pairs beyond
-            // the heap hold 0, which loses every comparison).  The ancestors of slot K that the push will meet are
-            // requested now as well and patched where the pop's path went through them.
-            int g[8];
-            unsigned int ck[7];
-            const bool right0 = !rank_lt(r[3], r[2]);
-            ck[0] = right0 ? r[3] : r[2];
-            const unsigned int hl = right0 ? r[6] : r[4], hr = right0 ? r[7] : r[5];
-            const bool right1 = !rank_lt(hr, hl);
-            ck[1] = right1 ? hr : hl;
-            g[0] = 1;
-            g[1] = 2 + (right0 ? 1 : 0);
-            g[2] = 2 * g[1] + (right1 ? 1 : 0);
-            const unsigned int q12 = H.get(12), q25 = H.get(25), q50 = H.get(50), q100 = H.get(100);
-#pragma unroll
-            for (int l = 2; l < 6; l += 2) {
-                const unsigned int pc = H.pair(g[l]), pl = H.pair(2 * g[l]), pr2 = H.pair(2 * g[l] + 1);
-                const unsigned int kl = pc & 0xffffu, kr = pc >> 16;
-                const bool right = !rank_lt(kr, kl);
-                ck[l] = right ? kr : kl;
-                g[l + 1] = 2 * g[l] + (right ? 1 : 0);
-                const unsigned int pg = right ? pr2 : pl;
-                const unsigned int gl = pg & 0xffffu, gr = pg >> 16;
-                const bool right2 = !rank_lt(gr, gl);
-                ck[l + 1] = right2 ? gr : gl;
-                g[l + 2] = 2 * g[l + 1] + (right2 ? 1 : 0);
-            }
-            {
-                const unsigned int pc = H.pair(g[6]);
-                const unsigned int kl = pc & 0xffffu, kr = pc >> 16;
-                const bool right = !rank_lt(kr, kl);
-                ck[6] = right ? kr : kl;
-                g[7] = 2 * g[6] + (right ? 1 : 0);
-            }
-            // the old last element climbs back from the leaf hole past every moved child that is smaller; the moved
-            // children are non-increasing down the path, so "it passes level l" is monotone in l
-            bool c[7];
-#pragma unroll
-            for (int l = 0; l < 7; l++) c[l] = rank_lt(ck[l], last);
-            unsigned int v[8];
-#pragma unroll
-            for (int l = 0; l < 8; l++) {
-                if (l == 0) v[l] = c[0] ? last : ck[0];
-                else if (l == 7) v[l] = c[6] ? ck[6] : last;
-                else v[l] = c[l - 1] ? ck[l - 1] : (c[l] ? last : ck[l]);
-            }
-            r[1] = v[0];
-            r[2] = right0 ? r[2] : v[1];
-            r[3] = right0 ? v[1] : r[3];
-#pragma unroll
-            for (int j = 4; j < 8; j++) r[j] = g[2] == j ? v[2] : r[j];
-#pragma unroll
-            for (int l = 3; l < 8; l++)
-                if (l < 6 || g[l] < K) H.set(g[l], v[l]);  // levels 3..5 are always inside the heap
-            // push_heap: the new element climbs from slot K along 100, 50, 25, 12, 6, 3, 1
-            static_assert(K == 200, "ancestor chain of slot K");
-            const unsigned int qv[7] = {r[1], r[3], r[6], g[3] == 12 ? v[3] : q12, g[4] == 25 ? v[4] : q25,
-                                        g[5] == 50 ? v[5] : q50, g[6] == 100 ? v[6] : q100};
-            bool pp[7];
-#pragma unroll
-            for (int u = 0; u < 7; u++) pp[u] = rank_lt(qv[u], y);
-            r[1] = pp[0] ? y : r[1];
-            r[3] = pp[1] ? (pp[0] ? qv[0] : y) : r[3];
-            r[6] = pp[2] ? (pp[1] ? qv[1] : y) : r[6];
-            constexpr int chain[7] = {1, 3, 6, 12, 25, 50, 100};
-#pragma unroll
-            for (int u = 3; u < 7; u++)
-                if (pp[u]) H.set(chain[u], pp[u - 1] ? qv[u - 1] : y);
-            last = pp[6] ? qv[6] : y;
-        }
-        if (((t + 1) & (TILE - 1)) == 0 && p < n) cpe[(t + 1) / TILE] = (unsigned short)r[1];
-    }
+    };
+    if (__ballot(on && has_tie) != 0ull) replay(std::true_type{});
+    else replay(std::false_type{});
     // ---- the heap array, slot order, for k_knn_finish ----
     if (lane < AWR) {
         H.set(K, last);
@@ -714,7 +767,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
         }
         return;
     }
-    const int n = packed & 0xffff, nle = packed >> 16;
+    const int n = packed & 0xffff, nle = (packed >> 16) & 0xfff;
     if (n < K) return;
     __shared__ unsigned short s_don[4][K];
     unsigned short *don = s_don[wave];

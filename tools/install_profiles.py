@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the summaries that tools/profile_all.sh left under gpurun_out/prof_<tag>/ into profiles/
 (<round>_<tag>_kernel_stats.csv, _bench_under_rocprof.json, _pmc_traffic.json, _pmc_sq.json, _occupancy.json) and rebuild
-profiles/<round>_traffic.json, the per-launch HBM bytes bench.py reports as roofline.traffic:
+profiles/<round>_traffic.json, the per-launch HBM bytes bench.py reports as roofline.traffic (means over the launches that did work: tools/profile.sh):
 (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 HBM note).  The road observation is
 two launches (k_map_obs or k_map_obs_set, then k_map_rows); their bytes are summed.  The file is stamped with the source
 hash of the build (bench.source_stamp): bench.py reports the traffic only for that build."""
@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 TAGS = ("exact_synthetic", "exact_waymo", "set_synthetic", "set_waymo", "lidar", "cfg3", "set_cfg3", "bev", "rl_loop")
 
 
@@ -62,8 +62,9 @@ for tag in TAGS:
         line = fh.read().strip().splitlines()[-1]
     with open(dst + "bench_under_rocprof.json", "w") as fh:
         fh.write(line + "\n")
-    for name in ("pmc_traffic_summary.json", "pmc_sq_summary.json"):
-        shutil.copy(os.path.join(src, name), dst + name.replace("_summary", ""))
+    for name in ("pmc_traffic_summary.json", "pmc_sq_summary.json", "kernel_work_summary.json"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), dst + name.replace("_summary", ""))
     with open(dst + "occupancy.json", "w") as fh:
         json.dump(occupancy_of(os.path.join(src, "trace")), fh, indent=1)
     with open(os.path.join(src, "pmc_traffic_summary.json")) as fh:
@@ -74,7 +75,8 @@ for tag in TAGS:
             continue
         f, w = c["FETCH_SIZE"]["mean"], c["WRITE_SIZE"]["mean"]
         entry[kern] = {"fetch_kib": f, "write_kib": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
-    road = sum(v["hbm_bytes_per_launch"] for k, v in entry.items() if k.startswith(("k_map_obs", "k_map_rows")))
+    # the road observation: every kernel launch_map_obs issues (selection or scan / rank / replay / finish, fallback, rows)
+    road = sum(v["hbm_bytes_per_launch"] for k, v in entry.items() if k.startswith(("k_map_obs", "k_map_rows", "k_knn_")))
     traffic[tag] = dict(hbm_bytes_per_launch=road, kernels=entry)
 with open(os.path.join(ROOT, "profiles", ROUND + "_traffic.json"), "w") as fh:
     json.dump(traffic, fh, indent=1)
