@@ -284,7 +284,10 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     if (d.rk_dbg == 1) return;
     int ci[NG];
 #pragma unroll
-    for (int g = 0; g < NG; g++) ci[g] = g * 64 + lane < nin ? (int)L.cidx[g * 64 + lane] : 0;
+    for (int g = 0; g < NG; g++) {
+        ci[g] = 0;
+        if (g * 64 < nin) ci[g] = g * 64 + lane < nin ? (int)L.cidx[g * 64 + lane] : 0;  // wave-uniform guard: a lane has 13 on average
+    }
     wave_sync();  // the index buffer becomes the sorted arrays
     // ---- exact keys (gd_math.hpp ego_dist2: the reference's arithmetic); every gather of the lane is in flight at once ----
     const float ex = in.ex, ey = in.ey, iw = in.iw, iz = in.iz;
@@ -328,9 +331,11 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     // (the bucket rides in the upper half of the road-index register: registers decide how many waves a SIMD holds)
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        const int b = bucket_of(key[g]);
-        ci[g] |= b << 16;
-        if (g * 64 + lane < nin) atomicAdd(&L.cnt2[b >> 1], 1u << ((b & 1) * 16));
+        if (g * 64 < nin) {  // wave-uniform
+            const int b = bucket_of(key[g]);
+            ci[g] |= b << 16;
+            if (g * 64 + lane < nin) atomicAdd(&L.cnt2[b >> 1], 1u << ((b & 1) * 16));
+        }
     }
     wave_sync();
     {
@@ -353,7 +358,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     if (d.rk_dbg == 3) return;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        if (g * 64 + lane < nin) {
+        if (g * 64 < nin && g * 64 + lane < nin) {
             const int b = ci[g] >> 16, sh = (b & 1) * 16;
             const int sl = (int)((atomicAdd(&L.cnt2[b >> 1], 1u << sh) >> sh) & 0xffffu);  // any order inside the bucket
             L.s.skey[sl] = key[g];
