@@ -69,12 +69,23 @@ for tag in TAGS:
         json.dump(occupancy_of(os.path.join(src, "trace")), fh, indent=1)
     with open(os.path.join(src, "pmc_traffic_summary.json")) as fh:
         pmc = json.load(fh)
+    # how often a kernel's launch does work at all (the trace run: k_map_obs is launched every step but selects only for the
+    # groups the rank replay could not take -- in the steady state none; the gated reset pass of the learner-side loop)
+    work = {}
+    if os.path.exists(os.path.join(src, "kernel_work_summary.json")):
+        with open(os.path.join(src, "kernel_work_summary.json")) as fh:
+            wj = json.load(fh)
+            # relative to the row kernel, which works in every pass that is not a gated empty one
+            ref = max([v["working_launches"] for k, v in wj.items() if k.startswith(("k_map_rows", "k_map_obs_set"))] + [1])
+            work = {k: min(1.0, v["working_launches"] / ref) for k, v in wj.items()}
     entry = {}
     for kern, c in pmc.items():
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             continue
         f, w = c["FETCH_SIZE"]["mean"], c["WRITE_SIZE"]["mean"]
-        entry[kern] = {"fetch_kib": f, "write_kib": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+        share = work.get(kern, 1.0)
+        entry[kern] = {"fetch_kib": f, "write_kib": w, "working_share_of_launches": share,
+                       "hbm_bytes_per_launch": (2 * f + w) * 1024 * share}
     # the road observation: every kernel launch_map_obs issues (selection or scan / rank / replay / finish, fallback, rows)
     road = sum(v["hbm_bytes_per_launch"] for k, v in entry.items() if k.startswith(("k_map_obs", "k_map_rows", "k_knn_")))
     traffic[tag] = dict(hbm_bytes_per_launch=road, kernels=entry)
