@@ -122,6 +122,10 @@ struct gd_sim {
     // signal pool then ran dry in the middle of a timed stretch and one hipLaunchKernel blocked the host for 14 ms --
     // tools/trace_gap.sh -- so that a 20-step wall clock was far above the sum of its kernels.)
     static constexpr size_t kEvRing = 32;
+    // second stream for the partner rows (k_partner_rows beside the road kernels): forked and joined with events, also
+    // inside the captured step graph
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool rk_alloc = false;  // the rank replay's buffers exist (reference order, k-NN)
     bool timing = false;
     std::vector<EventPair> ev_pool[gd::KERNEL_TIMED];
@@ -133,6 +137,9 @@ struct gd_sim {
     ~gd_sim() {
         (void)hipDeviceSynchronize();
         if (step_graph) (void)hipGraphExecDestroy(step_graph);
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         for (int i = 0; i < GD_T_COUNT; i++)
             if (owned[i] && exported[i]) (void)hipFree(exported[i]);
         for (void *p : internal) (void)hipFree(p);
@@ -176,7 +183,8 @@ struct gd_sim {
         }
     }
 
-    void launch(int which, bool move) {
+    void launch(int which, bool move, hipStream_t stream_override = nullptr) {
+        hipStream_t stream = stream_override ? stream_override : this->stream;
         const bool timed = timing && which < gd::KERNEL_TIMED && !d.gate_any;  // gated reset passes are mostly empty launches
         EventPair ep{};
         if (timed) {
@@ -264,6 +272,18 @@ struct gd_sim {
     // setupRestOfTasks, src/sim.cpp:785-943
     void run_rest(bool move) {
         launch(gd::KERNEL_STATE, move);
+        // GPUDRIVE_SPLIT_PARTNER=1 (off by default): the partner rows (148 MB of stores at 1024 x 64, nothing downstream of
+        // them in the step) on the second stream, beside the road kernels; joined before anything else of the caller's
+        // stream can follow.  Measured SLOWER in every workload (step, ms: synthetic 1.48 vs 1.42, Waymo tiles 0.68 vs
+        // 0.53, set order 0.43 vs 0.40): beside the road kernels the row kernel takes 86-273 us instead of 28 and the step
+        // waits for it at the join.
+        const bool fork = d.split_partner && !params.disableClassicalObs;
+        if (fork) {
+            HIP_CHECK(hipEventRecord(ev_fork, stream));
+            HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
+            launch(gd::KERNEL_PARTNER, move, side);
+            HIP_CHECK(hipEventRecord(ev_join, side));
+        }
         if (!params.disableClassicalObs) launch(gd::KERNEL_MAP_OBS, move);
         if (!params.disableClassicalObs && d.bev) {  // collectBevObservationsSystem, src/sim.cpp:879-884 (opt-in)
             launch(gd::KERNEL_BEV, move);
@@ -271,6 +291,7 @@ struct gd_sim {
         if (params.enableLidar) {  // lidarSystem, src/sim.cpp:895-913
             launch(gd::KERNEL_LIDAR, move);
         }
+        if (fork) HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
     }
 
     void upload_flags(int32_t *dst, const std::vector<int32_t> &flags) {
@@ -800,6 +821,11 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.A = A;
         d.p = *params;
         d.knn_order = cfg->knn_order;
+        // (not on the legacy null stream: it synchronises with every blocking stream and cannot be captured)
+        d.split_partner = (s->stream != nullptr && std::getenv("GPUDRIVE_SPLIT_PARTNER") != nullptr) ? 1 : 0;
+        HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
         d.step_dbg = std::getenv("GPUDRIVE_STEP_DBG") ? std::atoi(std::getenv("GPUDRIVE_STEP_DBG")) : 0;
         {
             (void)hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
@@ -1032,7 +1058,9 @@ int gd_set_stream(gd_sim *s, void *stream) {
     return guarded([&]() {
         HIP_CHECK(hipStreamSynchronize(s->stream));
         s->drop_graph();
+        HIP_CHECK(hipStreamSynchronize(s->side));
         s->stream = static_cast<hipStream_t>(stream);
+        s->d.split_partner = (s->stream != nullptr && std::getenv("GPUDRIVE_SPLIT_PARTNER") != nullptr) ? 1 : 0;
     });
 }
 

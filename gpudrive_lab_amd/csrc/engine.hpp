@@ -19,8 +19,8 @@
 
 namespace gd {
 
-// the first four are the timed kernels of gd_kernel_timing_read
-enum { KERNEL_STATE = 0, KERNEL_MAP_OBS = 1, KERNEL_LIDAR = 2, KERNEL_BEV = 3, KERNEL_RESET = 4, KERNEL_PADDING = 5, KERNEL_TIMED = 4 };
+// the first five are the timed kernels of gd_kernel_timing_read
+enum { KERNEL_STATE = 0, KERNEL_MAP_OBS = 1, KERNEL_LIDAR = 2, KERNEL_BEV = 3, KERNEL_PARTNER = 4, KERNEL_RESET = 5, KERNEL_PADDING = 6, KERNEL_TIMED = 5 };
 
 // Per-world broadphase grid header (see HostWorld in scene.hpp).
 struct GridHdr {
@@ -89,6 +89,7 @@ struct DevSim {
     const float2 *rcell_xy;        // the (x, y) of those roads, in the same (cell-sorted) order: one coalesced stream per grid row
     float4 *knn_prev;              // [W][A] {x, y, K-th key of the previous selection or +inf, 0}
     // reference-order road selection, rank replay (map_obs_rank.hip); rk_on = 0: k_map_obs alone selects
+    int split_partner;  // the partner rows are written by k_partner_rows (second stream) instead of k_world_step
     int step_dbg;  // diagnostic: k_world_step skips 1 = the road-box loop, 2 = the agent-agent loop, 3 = the partner rows (timing only)
     int rk_on;
     int rk_min_roads;  // worlds with fewer roads are selected by k_map_obs (the rank path's fixed costs do not pay there)

@@ -180,6 +180,60 @@ __global__ __launch_bounds__(A_T) void k_init_padding_rows(DevSim d) {
 // ------------------------------------------------------------------------------------------
 constexpr int STEP_THREADS = 256;  // agents live on threads [0, A); all threads write partner rows
 
+// collectPartnerObsSystem, src/sim.cpp:188-240, for one world by STEP_THREADS threads.  One thread per (ego, slot) row; a chunk
+// of STEP_THREADS consecutive 36-byte rows is assembled in LDS (row stride 9 floats: conflict-free) and leaves as whole
+// 16-byte pieces with streaming stores (a world's block starts at a multiple of 16 bytes and so does every chunk; only the
+// piece that straddles the end of the live egos' rows goes element by element).
+template <int A_T>
+__device__ __forceinline__ void partner_rows(const DevSim &d, int w, int n, int a, const float *s_px, const float *s_py,
+                                             const float *s_qw, const float *s_qz, const float *s_speed, const float *s_len,
+                                             const float *s_wid, const float *s_hgt, const int *s_etype, const int *s_id) {
+    {
+        __shared__ __attribute__((aligned(16))) float s_rows[STEP_THREADS * 9];
+        const int rows = n * (A_T - 1);
+        float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (int p0 = 0; p0 < rows; p0 += STEP_THREADS) {
+            if (d.step_dbg == 3) break;
+            const int p = p0 + a;
+            if (p < rows) {
+                const int ego = p / (A_T - 1), k = p - ego * (A_T - 1);
+                float *o = s_rows + a * 9;
+                if (k >= n - 1) {  // zero_nonexist(): id -2
+                    o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -2.f;
+                } else {
+                    const int j = k < ego ? k : k + 1;  // OtherAgents order, src/level_gen.cpp:450-464
+                    const Quat ego_inv = quat_inv(quat_from_wz(s_qw[ego], s_qz[ego]));
+                    const V3 r = quat_rotate(ego_inv, V3{s_px[j] - s_px[ego], s_py[j] - s_py[ego], 0.f});
+                    if (len_2(r.x, r.y) > d.p.observationRadius) {  // zero(): id -1
+                        o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -1.f;
+                    } else {
+                        const float heading = quat_to_yaw_row(quat_mul(ego_inv, quat_from_wz(s_qw[j], s_qz[j])));
+                        o[0] = s_speed[j];
+                        o[1] = r.x; o[2] = r.y;
+                        o[3] = heading;
+                        o[4] = s_len[j]; o[5] = s_wid[j]; o[6] = s_hgt[j];
+                        o[7] = (float)s_etype[j];
+                        o[8] = (float)s_id[j];
+                    }
+                }
+            }
+            __syncthreads();
+            const int nf = min(STEP_THREADS, rows - p0) * 9;  // floats of this chunk
+            float *out = base + (size_t)p0 * 9;
+            for (int q = a; q * 4 < nf; q += STEP_THREADS) {
+                if (q * 4 + 4 <= nf) {
+                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + q * 4));
+                } else {
+                    for (int e = q * 4; e < nf; e++) out[e] = s_rows[e];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+
 template <int A_T, bool MOVE>
 __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     const int w = blockIdx.x, a = threadIdx.x;
@@ -428,53 +482,30 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         ao[13] = (float)s_id[a];
     }
 
-    // ---- collectPartnerObsSystem, :188-240.  One thread per (ego, slot) row; a chunk of STEP_THREADS consecutive 36-byte rows
-    // is assembled in LDS (row stride 9 floats: conflict-free) and leaves as whole 16-byte pieces with streaming stores
-    // (a world's block starts at a multiple of 16 bytes and so does every chunk; only the piece that straddles the end
-    // of the live egos' rows goes element by element). ----
-    if (!d.p.disableClassicalObs) {
-        __shared__ __attribute__((aligned(16))) float s_rows[STEP_THREADS * 9];
-        const int rows = n * (A_T - 1);
-        float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        for (int p0 = 0; p0 < rows; p0 += STEP_THREADS) {
-            if (d.step_dbg == 3) break;
-            const int p = p0 + a;
-            if (p < rows) {
-                const int ego = p / (A_T - 1), k = p - ego * (A_T - 1);
-                float *o = s_rows + a * 9;
-                if (k >= n - 1) {  // zero_nonexist(): id -2
-                    o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -2.f;
-                } else {
-                    const int j = k < ego ? k : k + 1;  // OtherAgents order, src/level_gen.cpp:450-464
-                    const Quat ego_inv = quat_inv(quat_from_wz(s_qw[ego], s_qz[ego]));
-                    const V3 r = quat_rotate(ego_inv, V3{s_px[j] - s_px[ego], s_py[j] - s_py[ego], 0.f});
-                    if (len_2(r.x, r.y) > d.p.observationRadius) {  // zero(): id -1
-                        o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -1.f;
-                    } else {
-                        const float heading = quat_to_yaw_row(quat_mul(ego_inv, quat_from_wz(s_qw[j], s_qz[j])));
-                        o[0] = s_speed[j];
-                        o[1] = r.x; o[2] = r.y;
-                        o[3] = heading;
-                        o[4] = s_len[j]; o[5] = s_wid[j]; o[6] = s_hgt[j];
-                        o[7] = (float)s_etype[j];
-                        o[8] = (float)s_id[j];
-                    }
-                }
-            }
-            __syncthreads();
-            const int nf = min(STEP_THREADS, rows - p0) * 9;  // floats of this chunk
-            float *out = base + (size_t)p0 * 9;
-            for (int q = a; q * 4 < nf; q += STEP_THREADS) {
-                if (q * 4 + 4 <= nf) {
-                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + q * 4));
-                } else {
-                    for (int e = q * 4; e < nf; e++) out[e] = s_rows[e];
-                }
-            }
-            __syncthreads();
-        }
+    // ---- collectPartnerObsSystem, :188-240: here, or in k_partner_rows on a stream of its own beside the road kernels ----
+    if (!d.p.disableClassicalObs && !d.split_partner)
+        partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id);
+}
+
+// The same rows as a kernel of their own: the engine runs it on a second stream while the road kernels (which do not read the
+// partner rows) run on the first -- 148 MB of stores at 1024 x 64 that otherwise sit between two compute-bound phases.
+template <int A_T>
+__global__ __launch_bounds__(STEP_THREADS) void k_partner_rows(DevSim d) {
+    const int w = blockIdx.x, a = threadIdx.x;
+    if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
+    const int n = d.shape[w * 2 + 0];
+    __shared__ float s_px[A_T], s_py[A_T], s_qw[A_T], s_qz[A_T], s_speed[A_T], s_len[A_T], s_wid[A_T], s_hgt[A_T];
+    __shared__ int s_etype[A_T], s_id[A_T];
+    if (a < n) {
+        const size_t i = (size_t)w * A_T + a;
+        s_px[a] = d.px[i]; s_py[a] = d.py[i]; s_qw[a] = d.qw[i]; s_qz[a] = d.qz[i];
+        s_speed[a] = len_3(d.vx[i], d.vy[i], d.vz[i]);
+        s_len[a] = d.len[i]; s_wid[a] = d.wid[i]; s_hgt[a] = d.hgt[i];
+        s_etype[a] = d.etype[i];
+        s_id[a] = d.agent_id[i];
     }
+    __syncthreads();
+    partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id);
 }
 
 }  // namespace
@@ -493,6 +524,7 @@ static void launch_all(const DevSim &d, hipStream_t st, int which, bool move) {
         else hipLaunchKernelGGL((k_world_step<A_T, false>), grid, dim3(STEP_THREADS), 0, st, d);
         break;
     case KERNEL_MAP_OBS: launch_map_obs(d, st); break;
+    case KERNEL_PARTNER: hipLaunchKernelGGL(k_partner_rows<A_T>, grid, dim3(STEP_THREADS), 0, st, d); break;
     }
 }
 

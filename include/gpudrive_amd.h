@@ -219,7 +219,9 @@ int gd_stat(gd_sim *sim, int32_t which, int64_t *out);
 
 /* Timing hooks for the bench: HIP events around the named kernel on the engine's stream (a fixed ring of event pairs,
  * created by the enable call; steps run kernel by kernel, not from the hipGraph, while it is on).  Enabling again
- * while enabled zeroes the sums.  kernel: 0 = state step, 1 = road observation, 2 = LiDAR, 3 = BEV. */
+ * while enabled zeroes the sums.  kernel: 0 = state step, 1 = road observation, 2 = LiDAR, 3 = BEV,
+ * 4 = partner rows (on the engine's second stream, beside the road observation; no launches when they are written by the
+ * state step, which is the default; GPUDRIVE_SPLIT_PARTNER=1 moves them there). */
 int gd_kernel_timing_enable(gd_sim *sim, int32_t enable);
 int gd_kernel_timing_read(gd_sim *sim, int32_t kernel, double *total_ms, int64_t *launches);
 
