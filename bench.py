@@ -238,9 +238,9 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     if workload == "bev":
         names[3] = "k_bev"
     kt = {}
-    for kid, name in names.items():
+    for kid, kname in names.items():
         ms, n = sim.kernel_timing_read(kid)
-        kt[name] = dict(avg_us=1e3 * ms / max(n, 1), launches=n)
+        kt[kname] = dict(avg_us=1e3 * ms / max(n, 1), launches=n)
     # the partner rows run on the engine's second stream beside the road observation: timed, but not part of the sum that
     # the stretch's wall clock is compared with
     ms, n = sim.kernel_timing_read(4)
