@@ -18,63 +18,4 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$i -- python3 bench.py --steps 4 --warmup 1 --spin-ms 0 --no-cpu-baseline "$@" > $OUT/bench_pmc_$i.json 2>$OUT/pmc_$i.err
   i=$((i+1))
 done
-python3 - <<PY
-import csv,glob,collections,json,re
-out="$OUT"
-KERNELS=("k_map_obs_set","k_map_obs","k_map_rows","k_world_step","k_lidar","k_bev","k_pack_obs","k_episode_step","k_reset_worlds")
-def kname(k):
-    m=re.search(r"(k_[a-z_]+(<[^>]*>)?)",k)
-    return m.group(1) if m else None
-rows=[]
-for f in glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True):
-    rows+=list(csv.DictReader(open(f)))
-with open(out+"/kernel_stats_summary.csv","w") as fh:
-    if rows:
-        w=csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-for r in rows[:8]:
-    print({k:(v[:64] if isinstance(v,str) else v) for k,v in r.items() if k in ("Name","Calls","AverageNs","MinNs","MaxNs","Percentage")})
-# occupancy facts per kernel from the kernel trace
-occ={}
-for f in glob.glob(out+"/trace/**/*kernel_trace.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        n=kname(row.get("Kernel_Name",""))
-        if not n or n in occ: continue
-        g=lambda k: int(float(row.get(k,0) or 0))
-        vg=g("VGPR_Count")+g("Accum_VGPR_Count"); lds=g("LDS_Block_Size")
-        wg=max(1,g("Workgroup_Size_X"))*max(1,g("Workgroup_Size_Y"))*max(1,g("Workgroup_Size_Z"))
-        waves_wg=max(1,(wg+63)//64)
-        alloc=-(-max(vg,1)//8)*8
-        by_vgpr=min(8,512//alloc)
-        by_lds=(160*1024//lds)*waves_wg/4.0 if lds else 8
-        occ[n]=dict(vgpr=g("VGPR_Count"),agpr=g("Accum_VGPR_Count"),sgpr=g("SGPR_Count"),lds_bytes_per_workgroup=lds,workgroup_size=wg,
-                    grid_size=max(1,g("Grid_Size_X"))*max(1,g("Grid_Size_Y"))*max(1,g("Grid_Size_Z")),waves_per_simd_by_vgpr=by_vgpr,waves_per_simd_by_lds=min(8,by_lds),
-                    waves_per_simd=min(8,by_vgpr,by_lds))
-json.dump(occ, open(out+"/occupancy.json","w"), indent=1)
-agg=collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out+"/pmc_*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        n=kname(row["Kernel_Name"])
-        if n: agg[n][row["Counter_Name"]].append(float(row["Counter_Value"]))
-# launches that return at once (the gated reset pass of the learner-side loop finds no finished world; k_map_obs when no
-# group needs the fallback) would drag the per-launch means down: a dispatch counts only if its SQ_WAVES / FETCH / WRITE
-# value is at least 5 % of the kernel's largest
-for n,v in agg.items():
-    for c,x in list(v.items()):
-        if c in ("FETCH_SIZE","WRITE_SIZE") and x:
-            top=max(x); v[c]=[y for y in x if y>=0.05*top] or x
-# the same for the trace: averages over the dispatches that did work (>= 20 % of the kernel's longest)
-work=collections.defaultdict(list)
-for f in glob.glob(out+"/trace/**/*kernel_trace.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        n=kname(row.get("Kernel_Name",""))
-        if n: work[n].append(int(row["End_Timestamp"])-int(row["Start_Timestamp"]))
-with open(out+"/kernel_work_summary.json","w") as fh:
-    json.dump({n:dict(launches=len(x), working_launches=len([y for y in x if y>=0.2*max(x)]),
-                      avg_us_all=sum(x)/len(x)/1e3, avg_us_working=(lambda w: sum(w)/len(w)/1e3)([y for y in x if y>=0.2*max(x)]))
-               for n,x in sorted(work.items())}, fh, indent=1)
-traffic={k:{c:{"mean":sum(x)/len(x),"n":len(x)} for c,x in v.items() if c in ("FETCH_SIZE","WRITE_SIZE")} for k,v in agg.items()}
-sq={k:{c:sum(x)/len(x) for c,x in sorted(v.items()) if c.startswith("SQ_")} for k,v in agg.items()}
-json.dump(traffic, open(out+"/pmc_traffic_summary.json","w"), indent=1)
-json.dump(sq, open(out+"/pmc_sq_summary.json","w"), indent=1)
-print(json.dumps({k:{c:round(x["mean"]) for c,x in v.items()} for k,v in traffic.items()}))
-PY
+python3 tools/profile_summarize.py $OUT
