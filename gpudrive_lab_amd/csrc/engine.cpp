@@ -126,7 +126,29 @@ struct gd_sim {
     // inside the captured step graph
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool rk_alloc = false;  // the rank replay's buffers exist (reference order, k-NN)
+    bool rk_possible = false;  // reference order, k-NN, not switched off: a batch may take the rank replay
+    bool rk_alloc = false;     // its buffers exist
+
+    void ensure_rank_buffers() {
+        if (rk_alloc) return;
+        const size_t WA = static_cast<size_t>(W) * A;
+        d.rk_E = alloc_internal<uint16_t>(WA * GD_RANK_CAP + 64);  // the replay prefetches up to 24 entries past a row
+        d.rk_spc = alloc_internal<uint16_t>(WA * GD_RANK_CAP);
+        d.rk_heap = alloc_internal<uint32_t>(WA * GD_RANK_HEAP_DW);
+        d.rk_cpe = alloc_internal<uint16_t>(WA * GD_RANK_NCP);
+        d.rk_n = alloc_internal<int32_t>(WA);
+        d.rk_fallback = alloc_internal<int32_t>(WA / 32);
+        d.cp_road = alloc_internal<uint16_t>(2 * WA * GD_RANK_NCP);
+        d.cp_T = alloc_internal<float>(2 * WA * GD_RANK_NCP);
+        d.cp_hdr = alloc_internal<float4>(2 * WA);
+        d.rk_words = alloc_internal<uint32_t>(WA * GD_RANK_NCH);
+        d.rk_tl = alloc_internal<float>(WA);
+        d.rk_hist = alloc_internal<int32_t>(516);
+        d.rk_ticket = alloc_internal<int32_t>(WA);
+        d.rk_order = alloc_internal<int32_t>(WA);
+        d.road_bbox = alloc_internal<float4>(W);
+        rk_alloc = true;
+    }
     bool timing = false;
     std::vector<EventPair> ev_pool[gd::KERNEL_TIMED];
     size_t ev_head[gd::KERNEL_TIMED] = {};  // oldest recorded pair
@@ -567,7 +589,7 @@ struct gd_sim {
         d.boxes = static_cast<const float4 *>(d_boxes);
         HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
         choose_set_schedule();
-        if (rk_alloc) {
+        if (rk_possible) {
             // Which worlds take the rank replay (neither path changes a result).  Measured at 64 agent slots (road
             // observation, ms): 1024 worlds x 4096 roads 1.53 ranked / 1.84 on keys; 1024 Waymo tiles (346-873 roads) 0.58 /
             // 0.47 -- there k_map_obs is one short generation of workgroups and the rank kernels' fixed costs do not pay;
@@ -581,6 +603,10 @@ struct gd_sim {
             d.rk_on = 0;
             for (int w = 0; w < W; w++)
                 if (road_off[w + 1] - road_off[w] >= std::max(d.rk_min_roads, GD_MAP_OBS_K)) d.rk_on = 1;
+            if (d.rk_on) {
+                ensure_rank_buffers();
+                reset_rank_state();
+            }
         }
         {
             // one BEV workgroup per LIVE agent: a workgroup that only finds out it has no agent still has to be given
@@ -683,20 +709,23 @@ struct gd_sim {
         std::vector<float> prev(static_cast<size_t>(W) * A * 4, 0.f);
         for (size_t i = 0; i < static_cast<size_t>(W) * A; i++) prev[i * 4 + 2] = INFINITY;
         HIP_CHECK(hipMemcpy(d.knn_prev, prev.data(), prev.size() * sizeof(float), hipMemcpyHostToDevice));
-        if (rk_alloc) {  // likewise no checkpoint of a previous selection: the next one takes the fallback
-            HIP_CHECK(hipMemset(d.cp_hdr, 0, sizeof(float4) * 2 * static_cast<size_t>(W) * A));
-            std::vector<float> bb(static_cast<size_t>(W) * 4);
-            for (int w = 0; w < W; w++) {
-                float lo_x = INFINITY, lo_y = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY;
-                for (size_t r = 0; r * 2 < w_xy[w].size(); r++) {
-                    lo_x = std::min(lo_x, w_xy[w][2 * r]); hi_x = std::max(hi_x, w_xy[w][2 * r]);
-                    lo_y = std::min(lo_y, w_xy[w][2 * r + 1]); hi_y = std::max(hi_y, w_xy[w][2 * r + 1]);
-                }
-                bb[w * 4 + 0] = lo_x; bb[w * 4 + 1] = lo_y; bb[w * 4 + 2] = hi_x; bb[w * 4 + 3] = hi_y;
+    }
+
+    // No checkpoint of a previous selection survives a change of the worlds' roads or agent slots: the next selection of
+    // every agent takes the fallback, which records fresh ones.
+    void reset_rank_state() {
+        HIP_CHECK(hipMemset(d.cp_hdr, 0, sizeof(float4) * 2 * static_cast<size_t>(W) * A));
+        std::vector<float> bb(static_cast<size_t>(W) * 4);
+        for (int w = 0; w < W; w++) {
+            float lo_x = INFINITY, lo_y = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY;
+            for (size_t r = 0; r * 2 < w_xy[w].size(); r++) {
+                lo_x = std::min(lo_x, w_xy[w][2 * r]); hi_x = std::max(hi_x, w_xy[w][2 * r]);
+                lo_y = std::min(lo_y, w_xy[w][2 * r + 1]); hi_y = std::max(hi_y, w_xy[w][2 * r + 1]);
             }
-            HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemset(d.rk_fallback, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
+            bb[w * 4 + 0] = lo_x; bb[w * 4 + 1] = lo_y; bb[w * 4 + 2] = hi_x; bb[w * 4 + 3] = hi_y;
         }
+        HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d.rk_fallback, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
     }
 
     void do_reset(const std::vector<int32_t> &flags) {
@@ -826,7 +855,10 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-        d.step_dbg = std::getenv("GPUDRIVE_STEP_DBG") ? std::atoi(std::getenv("GPUDRIVE_STEP_DBG")) : 0;
+        d.step_dbg = 0;
+#ifdef GD_DIAG
+        if (const char *e = std::getenv("GPUDRIVE_STEP_DBG")) d.step_dbg = std::atoi(e);
+#endif
         {
             (void)hipDeviceGetAttribute(&s->cu_count, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
             d.set_fused_rows = 0;  // chosen with the worlds (rebuild_worlds -> choose_set_schedule)
@@ -889,30 +921,16 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.grid = s->alloc_internal<gd::GridHdr>(W);
         d.rgrid = s->alloc_internal<gd::GridHdr>(W);
         d.knn_prev = s->alloc_internal<float4>(WA);
-        // rank replay of the reference-order selection (map_obs_rank.hip): a fallback group is one workgroup of k_map_obs
+        // rank replay of the reference-order selection (map_obs_rank.hip): a fallback group is one workgroup of k_map_obs.
+        // Its buffers (7.4 KB per agent slot) are allocated when a batch first takes the path (rebuild_worlds).
         d.rk_on = 0;
-        if (GD_MAP_OBS_AW == 32 && cfg->knn_order != GD_KNN_SET_ORDER && params->roadObservationAlgorithm == GD_ROADS_K_NEAREST &&
-            std::getenv("GPUDRIVE_NO_RANK_REPLAY") == nullptr) {
-            d.rk_on = 1;
-            d.rk_min_roads = 1536;  // chosen with the worlds (rebuild_worlds)
-            s->rk_alloc = true;
-            d.rk_dbg = std::getenv("GPUDRIVE_RANK_DBG") ? std::atoi(std::getenv("GPUDRIVE_RANK_DBG")) : 0;
-            d.rk_E = s->alloc_internal<uint16_t>(WA * GD_RANK_CAP + 64);  // the replay prefetches up to 24 entries past a row
-            d.rk_spc = s->alloc_internal<uint16_t>(WA * GD_RANK_CAP);
-            d.rk_heap = s->alloc_internal<uint32_t>(WA * GD_RANK_HEAP_DW);
-            d.rk_cpe = s->alloc_internal<uint16_t>(WA * GD_RANK_NCP);
-            d.rk_n = s->alloc_internal<int32_t>(WA);
-            d.rk_fallback = s->alloc_internal<int32_t>(WA / 32);
-            d.cp_road = s->alloc_internal<uint16_t>(2 * WA * GD_RANK_NCP);
-            d.cp_T = s->alloc_internal<float>(2 * WA * GD_RANK_NCP);
-            d.cp_hdr = s->alloc_internal<float4>(2 * WA);
-            d.rk_words = s->alloc_internal<uint32_t>(WA * GD_RANK_NCH);
-            d.rk_tl = s->alloc_internal<float>(WA);
-            d.rk_hist = s->alloc_internal<int32_t>(516);
-            d.rk_ticket = s->alloc_internal<int32_t>(WA);
-            d.rk_order = s->alloc_internal<int32_t>(WA);
-            d.road_bbox = s->alloc_internal<float4>(W);
-        }
+        d.rk_dbg = 0;
+        d.rk_min_roads = 1536;
+        s->rk_possible = GD_MAP_OBS_AW == 32 && cfg->knn_order != GD_KNN_SET_ORDER &&
+                         params->roadObservationAlgorithm == GD_ROADS_K_NEAREST && std::getenv("GPUDRIVE_NO_RANK_REPLAY") == nullptr;
+#ifdef GD_DIAG
+        if (const char *e = std::getenv("GPUDRIVE_RANK_DBG")) d.rk_dbg = std::atoi(e);
+#endif
         for (int i = 0; i < gd_sim::kRing; i++) {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->h_flags[i]), sizeof(int32_t) * W, hipHostMallocDefault));
             HIP_CHECK(hipEventCreateWithFlags(&s->flag_ev[i], hipEventDisableTiming));

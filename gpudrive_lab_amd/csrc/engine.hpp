@@ -17,6 +17,14 @@
 #define GD_RANK_HEAP_DW 104
 #define GD_RANK_NCH 320  // candidate words per agent: 32 roads each, kMaxRoadEntityCount = 10,000
 
+// Phase switches for timing experiments exist only in diagnostic builds (-DGD_DIAG); in the product library the
+// condition is the constant false and the compiler drops the code.
+#ifdef GD_DIAG
+#define GD_DIAG_IS(field, value) ((field) == (value))
+#else
+#define GD_DIAG_IS(field, value) false
+#endif
+
 namespace gd {
 
 // the first five are the timed kernels of gd_kernel_timing_read
@@ -90,10 +98,11 @@ struct DevSim {
     float4 *knn_prev;              // [W][A] {x, y, K-th key of the previous selection or +inf, 0}
     // reference-order road selection, rank replay (map_obs_rank.hip); rk_on = 0: k_map_obs alone selects
     int split_partner;  // the partner rows are written by k_partner_rows (second stream) instead of k_world_step
-    int step_dbg;  // diagnostic: k_world_step skips 1 = the road-box loop, 2 = the agent-agent loop, 3 = the partner rows (timing only)
+    int step_dbg;  // -DGD_DIAG builds only (tools/build_expt.sh): k_world_step skips 1 = the road-box loop, 2 = the agent-agent
+                   // loop, 3 = the partner rows; timing only, results wrong.  The product build compiles the switches out (GD_DIAG_IS).
     int rk_on;
     int rk_min_roads;  // worlds with fewer roads are selected by k_map_obs (the rank path's fixed costs do not pay there)
-    int rk_dbg;  // diagnostic: k_knn_rank stops after phase n (timing only; results are wrong)
+    int rk_dbg;  // -DGD_DIAG builds only: k_knn_rank stops after phase n (timing only; results are wrong)
     uint16_t *rk_E;        // [W][A][CAP] rank of every candidate, candidate (= road) order
     uint16_t *rk_spc;      // [W][A][CAP] sorted slot -> road index
     uint32_t *rk_heap;     // [W][A][GD_RANK_HEAP_DW] the replayed heap array as rank pairs

@@ -194,7 +194,7 @@ __device__ __forceinline__ void partner_rows(const DevSim &d, int w, int n, int 
         float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
         typedef float f4 __attribute__((ext_vector_type(4)));
         for (int p0 = 0; p0 < rows; p0 += STEP_THREADS) {
-            if (d.step_dbg == 3) break;
+            if (GD_DIAG_IS(d.step_dbg, 3)) break;
             const int p = p0 + a;
             if (p < rows) {
                 const int ego = p / (A_T - 1), k = p - ego * (A_T - 1);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
             const bool me_static = (my_fl & 2) != 0;
             int hit = 0;  // bit 0 collided, bits 1..3 info0..info2
             for (int j = part; j < n; j += P) {
-                if (d.step_dbg == 2) break;
+                if (GD_DIAG_IS(d.step_dbg, 2)) break;
                 if (j == ag) continue;
                 const int fl = s_flags[j];
                 if (!(fl & 1)) continue;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
                 else if (otype == ET_Vehicle) hit |= 4;
                 else if (otype <= ET_Cyclist) hit |= 8;
             }
-            if (!me_static && d.step_dbg != 1) {
+            if (!me_static && !GD_DIAG_IS(d.step_dbg, 1)) {
                 // road boxes of the broadphase cell under the agent's centre
                 const GridHdr gh = d.grid[w];
                 const float fx = (mx - gh.ox) * gh.inv_cell, fy = (my - gh.oy) * gh.inv_cell;

@@ -281,7 +281,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         return;
     }
     wave_sync();
-    if (d.rk_dbg == 1) return;
+    if (GD_DIAG_IS(d.rk_dbg, 1)) return;
     int ci[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) {
@@ -313,7 +313,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         kmax_seen = fmaxf(kmax_seen, __shfl_xor(kmax_seen, off));
     }
     const float t_last = in.t_last;
-    if (d.rk_dbg == 2) return;
+    if (GD_DIAG_IS(d.rk_dbg, 2)) return;
 
     // ---- ranks.  Counting sort into NB buckets (a monotone function of the key: linear up to 1.5 x the previous
     // K-th key, where most candidates lie, logarithmic beyond), then the exact order inside each bucket ----
@@ -355,7 +355,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
     }
     wave_sync();
-    if (d.rk_dbg == 3) return;
+    if (GD_DIAG_IS(d.rk_dbg, 3)) return;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         if (g * 64 < nin && g * 64 + lane < nin) {
@@ -366,7 +366,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
     }
     wave_sync();
-    if (d.rk_dbg == 4) return;
+    if (GD_DIAG_IS(d.rk_dbg, 4)) return;
     const unsigned short *cur16 = reinterpret_cast<const unsigned short *>(L.cnt2);  // cursor of bucket b = its END
     int too_many_ties = 0, any_tie = 0;
     unsigned int e[NG];
@@ -407,7 +407,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         // larger buckets: the four candidates advance together (one LDS round trip per step, not four)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off));
-        if (d.rk_dbg == 7) longest = 0;
+        if (GD_DIAG_IS(d.rk_dbg, 7)) longest = 0;
         for (int j = M; j < longest; j++) {
             float mkk[U];
             int mpp[U];
@@ -432,7 +432,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
     }
     wave_sync();  // every read of the sorted arrays is done: their space becomes the slot -> road table
-    if (d.rk_dbg == 5) return;
+    if (GD_DIAG_IS(d.rk_dbg, 5)) return;
     if (__ballot(too_many_ties != 0) != 0ull) {
         if (lane == 0) {
             d.rk_n[i] = 0;

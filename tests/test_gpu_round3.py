@@ -127,6 +127,26 @@ def test_rank_replay_lockstep_with_the_oracle_through_a_whole_episode(oracle_mod
     gpu.close()
 
 
+def test_partner_rows_on_the_second_stream(oracle_mod, monkeypatch):
+    """GPUDRIVE_SPLIT_PARTNER=1 (off by default: measured slower): the partner rows are written by
+    k_partner_rows on the engine's second stream, forked and joined inside the captured step graph.  Same rows, on the null
+    stream (where the switch is ignored) and on a side stream through graph replay and plain reset passes."""
+    import torch
+    monkeypatch.setenv("GPUDRIVE_SPLIT_PARTNER", "1")
+    scenes = [SCENE_4, TEST_JSON, SCENE_407]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        gpu = P.make_gpu_sim(scenes, max_agents=64, **CLASSIC)
+        orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **CLASSIC)
+        P.compare_fresh(gpu, orc)
+        P.lockstep(gpu, orc, 6, 0, seed=41)
+        assert gpu.stat(0) > 0, "the step graph (with its fork and join) was not replayed"
+        gpu.reset([1])
+        orc.reset([1])
+        P.compare_fresh(gpu, orc)
+    P.lockstep(gpu, orc, 2, 0, seed=42)   # back on the null stream: written by the state step again
+    gpu.close()
+
+
 # ---- BASELINE.json full sizes against the oracle ----
 def _tiled(n):
     base = [TEST_JSON, SCENE_407, SCENE_4]
