@@ -93,7 +93,8 @@ def params_for(workload):
     kw = dict(observationRadius=50.0, collisionBehaviour=2, rewardType=1, distanceToGoalThreshold=2.0,
               dynamicsModel=0, roadObservationAlgorithm=0, isStaticAgentControlled=1,
               initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
-    kw["polylineReductionThreshold"] = 0.0 if workload in ("synthetic", "rl_loop") else 0.1
+    # "waymo_raw": the Waymo tiles with unreduced polylines (5-10 thousand roads per world; not in the default list)
+    kw["polylineReductionThreshold"] = 0.0 if workload in ("synthetic", "rl_loop", "waymo_raw") else 0.1
     if workload == "lidar":  # BASELINE configs[4]: LiDAR 3 x 50 rays, mixed vehicle / cyclist / pedestrian agents
         kw["enableLidar"] = 1
     if workload == "cfg3":   # BASELINE configs[2]: 4 x the worlds, collisions stop agents, goal-reach reward

@@ -138,6 +138,7 @@ struct gd_sim {
         d.rk_cpe = alloc_internal<uint16_t>(WA * GD_RANK_NCP);
         d.rk_n = alloc_internal<int32_t>(WA);
         d.rk_fallback = alloc_internal<int32_t>(WA / 32);
+        d.rk_streak = alloc_internal<int32_t>(WA / 32);
         d.cp_road = alloc_internal<uint16_t>(2 * WA * GD_RANK_NCP);
         d.cp_T = alloc_internal<float>(2 * WA * GD_RANK_NCP);
         d.cp_hdr = alloc_internal<float4>(2 * WA);
@@ -600,9 +601,17 @@ struct gd_sim {
             for (int w = 0; w < W; w++) groups += (w_agents[w] + 31) / 32;
             const char *pin = std::getenv("GPUDRIVE_RANK_MIN_ROADS");
             d.rk_min_roads = pin ? std::atoi(pin) : (groups > 3 * 4 * cu_count ? GD_MAP_OBS_K : 1536);
+            // and not the largest worlds: with 200 ln(R / 200) inserts per agent and the superset on top, unreduced Waymo
+            // scenes (5-10 thousand roads) overflow the 1280-candidate buffer for one agent in eight, which sends every group
+            // of 32 to the fallback (measured: 3.80 ms ranked + fallback against 3.39 on keys alone).  Groups that keep
+            // overflowing below this size bypass the rank kernels on their own (rk_streak).
+            const char *pin_max = std::getenv("GPUDRIVE_RANK_MAX_ROADS");
+            d.rk_max_roads = pin_max ? std::atoi(pin_max) : 6000;
             d.rk_on = 0;
-            for (int w = 0; w < W; w++)
-                if (road_off[w + 1] - road_off[w] >= std::max(d.rk_min_roads, GD_MAP_OBS_K)) d.rk_on = 1;
+            for (int w = 0; w < W; w++) {
+                const int R = road_off[w + 1] - road_off[w];
+                if (R >= std::max(d.rk_min_roads, GD_MAP_OBS_K) && R <= d.rk_max_roads) d.rk_on = 1;
+            }
             if (d.rk_on) {
                 ensure_rank_buffers();
                 reset_rank_state();
@@ -726,6 +735,7 @@ struct gd_sim {
         }
         HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemset(d.rk_fallback, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
+        HIP_CHECK(hipMemset(d.rk_streak, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
     }
 
     void do_reset(const std::vector<int32_t> &flags) {
@@ -1171,7 +1181,7 @@ int gd_debug_road_path(gd_sim *s, int32_t *out) {
         HIP_CHECK(hipMemcpy(why.data(), s->d.rk_ticket, WA * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < WA; i++) {
             if (out[i] > 0) out[i] = out[i] == (1 << 30) ? -3 : (out[i] & 0xffff);
-            else if (out[i] == -1 && why[i] < -1) out[i] = -10 + (why[i] + 2);  // -10 no checkpoints / small world, -11 overflow, -12 ties
+            else if (out[i] == -1 && why[i] < -1) out[i] = -10 + (why[i] + 2);  // -10 no checkpoints / small world, -11 overflow, -12 ties, -13 bypass
         }
     });
 }

@@ -101,13 +101,14 @@ struct DevSim {
     int step_dbg;  // -DGD_DIAG builds only (tools/build_expt.sh): k_world_step skips 1 = the road-box loop, 2 = the agent-agent
                    // loop, 3 = the partner rows; timing only, results wrong.  The product build compiles the switches out (GD_DIAG_IS).
     int rk_on;
+    int rk_max_roads;  // ... and worlds with more: their agents' candidates (200 ln(R / 200) inserts and more) overflow the buffer too often
     int rk_min_roads;  // worlds with fewer roads are selected by k_map_obs (the rank path's fixed costs do not pay there)
     int rk_dbg;  // -DGD_DIAG builds only: k_knn_rank stops after phase n (timing only; results are wrong)
     uint16_t *rk_E;        // [W][A][CAP] rank of every candidate, candidate (= road) order
     uint16_t *rk_spc;      // [W][A][CAP] sorted slot -> road index
     uint32_t *rk_heap;     // [W][A][GD_RANK_HEAP_DW] the replayed heap array as rank pairs
     uint16_t *rk_cpe;      // [W][A][NCP] rank on top of the heap at every checkpoint of this selection
-    int32_t *rk_hist;      // [513] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path
+    int32_t *rk_hist;      // [514] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path, selections so far
     int32_t *rk_ticket;    // [W][A] bin << 20 | place inside the bin; -1 = not on the rank path this step
     int32_t *rk_order;     // [W][A] agents on the rank path, most candidates first
     uint32_t *rk_words;    // [W][A][NCH] candidate bits of 32 roads, one row per agent (k_knn_scan -> k_knn_rank)
@@ -115,6 +116,8 @@ struct DevSim {
     const float4 *road_bbox;  // [W] (min x, min y, max x, max y) over the world's roads
     int32_t *rk_n;         // [W][A] candidates | in-radius candidates << 16; 0 = not on the rank path this step; 1 << 30 = too far from every road
     int32_t *rk_fallback;  // [W * A / 32] group of 32 agent slots must be selected by k_map_obs this step
+    int32_t *rk_streak;    // [W * A / 32] consecutive selections in which the group needed the fallback: from 3 on the group
+                           // bypasses the rank kernels (whose work would be wasted) and retries every 64th selection
     // checkpoints of the previous selection of every agent: the K-th key (cp_T) that the heap held when the scan reached road
     // cp_road; cp_hdr = {x, y, number of checkpoints as int bits (0: none usable), 0} where they were recorded
     // two sets: [0] the previous selection, [1] the selection at the start of the episode (where a reset puts the agent back)

@@ -809,7 +809,10 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
                 d.cp_hdr[WA + i] = make_float4(ex, ey, __int_as_float(cp_count), 0.f);
             }
         }
-        if (lane == 0) d.rk_fallback[slot] = 0;  // read at the top by every lane of this (only) wave of the group
+        if (lane == 0) {
+            d.rk_fallback[slot] = 0;  // read at the top by every lane of this (only) wave of the group
+            d.rk_streak[slot] = min(d.rk_streak[slot] + 1, 1 << 20);  // k_knn_finish zeroes it when the group gets through
+        }
     }
     STAMP(t_w0);
     store_selection<A_T>(d, w, a0, min(AW, n - a0), [&](int c, int sl) -> int { return s_idx[(sl + 1) * AW + idx_col(c)]; }, lane, 64);

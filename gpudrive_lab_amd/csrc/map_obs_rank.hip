@@ -120,11 +120,16 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
                 const float m1 = n1 > 0 ? sqrtf((ex - h1.x) * (ex - h1.x) + (ey - h1.y) * (ey - h1.y)) : __builtin_inff();
                 const int set = m1 < m0 ? 1 : 0;
                 const float move = set ? m1 : m0;
-                ncp = (R >= K && R >= d.rk_min_roads) ? (set ? n1 : n0) : 0;  // small worlds: k_map_obs is as fast
-                if (ncp <= 0) {
+                ncp = (R >= K && R >= d.rk_min_roads && R <= d.rk_max_roads) ? (set ? n1 : n0) : 0;  // small worlds: k_map_obs is
+                                                                                                   // as fast; the largest overflow
+                // a group that needed the fallback three selections in a row (worlds whose agents overflow the candidate
+                // buffer) stops paying for rank kernels whose work is thrown away; it tries again every 64th selection
+                const int grp = (int)(i / 32);
+                const bool bypass = ncp > 0 && d.rk_streak[grp] >= 3 && ((d.rk_hist[513] + grp) & 63) != 0;
+                if (ncp <= 0 || bypass) {
                     state = 0;
                     ncp = 0;
-                    reason = -2;  // no usable checkpoints, or a world below rk_min_roads
+                    reason = bypass ? -5 : -2;  // -2: no usable checkpoints, or a world below rk_min_roads
                     d.rk_fallback[i / 32] = 1;
                 } else {
                     const float iw = d.qw[i], iz = d.qz[i];
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
     }
     __syncthreads();
     const int ncp = s_ncp[lane];
+    if (__syncthreads_or(ncp > 0 ? 1 : 0) == 0) return;  // no agent of this workgroup is on the rank path (far, fallback, bypass)
     int q = -1;  // checkpoint in force for this lane
     const int nch = (R + 31) >> 5;
     // A wave takes 16 consecutive chunks of the tile, 8 at a time: the agents' words of a batch are handed over agent-major
@@ -516,7 +522,10 @@ __global__ __launch_bounds__(256) void k_knn_bins(DevSim d) {
     for (int k = 0; k < (t >> 6); k++) before += s_part[k];
     d.rk_hist[256 + t] = before + incl - c;  // start of bin t
     d.rk_hist[t] = 0;                        // ready for the next selection
-    if (t == 255) d.rk_hist[512] = before + incl;  // agents on the rank path
+    if (t == 255) {
+        d.rk_hist[512] = before + incl;  // agents on the rank path
+        d.rk_hist[513]++;                // selections so far (k_knn_scan staggers the retries of bypassing groups with it)
+    }
 }
 
 __global__ __launch_bounds__(256) void k_knn_order(DevSim d) {
@@ -848,6 +857,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
         }
     }
     if (lane == 0) {
+        d.rk_streak[i / 32] = 0;  // the group got through without the fallback
         d.cp_hdr[i] = make_float4(ex, ey, __int_as_float(ncp), 0.f);
         if (at_start) d.cp_hdr[WA + i] = make_float4(ex, ey, __int_as_float(ncp), 0.f);
         d.sel_hdr[(size_t)i * 2] = make_float4(ex, ey, qw, qz);

@@ -232,7 +232,8 @@ int gd_debug_set_state(gd_sim *sim, const float *host_in);
 /* Which kernel selected every agent slot's roads in the last reference-order selection: > 0 the rank replay
  * (map_obs_rank.hip; the value is the agent's candidate count), -1 the history replay on keys (k_map_obs, the fallback:
  * first selection after a map change, jumps, overflow; -1 because another agent of its group of 32 needed it, -10 no usable
- * checkpoints or a world too small for the rank path, -11 more candidates than the buffer holds, -12 more than 32 equal keys), -3 no road of the world within reach of the radius (no rows),
+ * checkpoints or a world too small for the rank path, -11 more candidates than the buffer holds, -12 more than 32 equal keys, -13 the group bypasses the rank kernels
+ * after three fallbacks in a row and retries every 64th selection), -3 no road of the world within reach of the radius (no rows),
  * 0 no selection (padding slot), -2 the rank replay is not in use (set order, linear scan, GPUDRIVE_NO_RANK_REPLAY).  out: [W][A] int32 on the host. */
 int gd_debug_road_path(gd_sim *sim, int32_t *out);
 

@@ -60,6 +60,7 @@ def test_rank_replay_equals_history_replay_bit_for_bit(bench_scenes, tmp_path, m
         # histories) and take the fallback, the duplicated-polyline world is ranked with its equal keys
         scenes, kw, min_taken = [_dup_scene(tmp_path), SCENE_407], dict(BENCH, observationRadius=200.0), 0.4
     monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")   # small worlds too (by default k_map_obs keeps those)
+    monkeypatch.setenv("GPUDRIVE_RANK_MAX_ROADS", "20000")  # and the largest (by default left to k_map_obs as well)
     fast = P.make_gpu_sim(scenes, max_agents=64, **kw)
     monkeypatch.setenv("GPUDRIVE_NO_RANK_REPLAY", "1")
     slow = P.make_gpu_sim(scenes, max_agents=64, **kw)

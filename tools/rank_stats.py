@@ -16,11 +16,13 @@ for k in range(40):
     if k in (0, 1, 2, 5, 10, 20, 39):
         p = sim.debug_road_path()
         live = p != 0
-        fb = (p == -1)
+        fb = (p == -1) | (p <= -10)
         far = (p == -3)
+        import collections
+        why = collections.Counter(p[p <= -10].tolist())
         n = p[p > 0]
         # agents that individually overflowed: fallback groups are 32 wide
-        print("step %2d: far %d" % (k + 1, far.sum()), end=" ")
+        print("step %2d: far %d reasons %s" % (k + 1, far.sum(), dict(why)), end=" ")
         print("step %2d: live %d, fallback agents %d (%.1f%%), rank agents %d; candidates mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d" %
               (k + 1, live.sum(), fb.sum(), 100.0 * fb.sum() / max(live.sum(), 1), (p > 0).sum(),
                n.mean() if n.size else 0, *(np.percentile(n, [50, 90, 99]) if n.size else (0, 0, 0)), n.max() if n.size else 0))
