@@ -403,7 +403,7 @@ struct Drain {
 // this agent's column of the ring (slot c at ring[c * AW]), `head` the number of chunks scanned so far.
 // `cpr` / `cpt`: this agent's checkpoint rows (engine.hpp cp_road / cp_T; null when the rank path is off): after every
 // 32nd candidate the K-th key in force is recorded together with the first road it holds for (rounded up to a whole
-// 64-road piece) -- what map_obs_rank.hip bounds the agent's next selection with.
+// 32-road chunk) -- what map_obs_rank.hip bounds the agent's next selection with.
 __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Drain &s, const unsigned int *ring, const float2 *rxy,
                                             int head, float ex, float ey, float iw, float iz, bool owner,
                                             unsigned short *cpr, float *cpt) {
@@ -422,7 +422,7 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
     if (s.has) {
         s.done++;
         if (cpr != nullptr && (s.done & 31) == 0 && (s.done >> 5) < GD_RANK_NCP && owner) {
-            cpr[s.done >> 5] = (unsigned short)min(65535, (s.r_cur + 1 + 63) & ~63);
+            cpr[s.done >> 5] = (unsigned short)min(65535, (s.r_cur + 1 + 31) & ~31);
             cpt[s.done >> 5] = top.tk[1];
         }
     }
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
             heap.load(top);
             wave_sync();  // every lane of an agent has read slot K before its sentinel value is visible
             if (cpr != nullptr && owner && live) {  // checkpoint 0: the heap of the first K roads
-                cpr[0] = (unsigned short)((K / 64) * 64);
+                cpr[0] = (unsigned short)((K / 32) * 32);
                 cpt[0] = top.tk[1];
             }
 #ifdef GD_STAMPS

@@ -450,7 +450,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     // where this selection's checkpoints start to apply (their K-th distances are filled in by k_knn_finish):
     // checkpoint 0 is the heap of the first K roads (road indices below K are candidates regardless), checkpoint q
     // the heap after candidate K + 32 q - 1, which holds for every road behind that candidate; rounded up to whole
-    // 64-road pieces of the scan
+    // 32-road chunks of the scan
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const int p = g * 64 + lane;
@@ -460,10 +460,10 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             L.spc[(int)(e[g] >> 5) - 1 + (int)(e[g] & 31u)] = (unsigned short)road;
             const int t = p - K + 1;  // candidates beyond the first K up to and including this one
             if (t > 0 && (t & (TILE - 1)) == 0)
-                d.cp_road[(size_t)i * NCP + t / TILE] = (unsigned short)min(65535, (road + 1 + 63) & ~63);
+                d.cp_road[(size_t)i * NCP + t / TILE] = (unsigned short)min(65535, (road + 1 + 31) & ~31);
         }
     }
-    if (lane == 0) d.cp_road[(size_t)i * NCP] = (unsigned short)((K / 64) * 64);
+    if (lane == 0) d.cp_road[(size_t)i * NCP] = (unsigned short)((K / 32) * 32);
     wave_sync();
     for (int s = lane; s < nin; s += 64) d.rk_spc[(size_t)i * CAP + s] = L.spc[s];
     const bool has_tie = __ballot(any_tie != 0) != 0ull;  // the replay then compares ranks without their tie field
