@@ -1105,7 +1105,25 @@ int gd_attach_bev(gd_sim *s, float *bev) {
 }
 
 int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
-    if (!s || !out || which < 0 || which > 7) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
+#ifdef GD_DIAG
+    constexpr int32_t kLastStat = 9;
+#else
+    constexpr int32_t kLastStat = 7;
+#endif
+    if (!s || !out || which < 0 || which > kLastStat) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
+#ifdef GD_DIAG
+    if (which == 8 || which == 9) {  // diagnostic build: most crowded ranking bucket / slowest agent (cycles / 64) since last read
+        *out = 0;
+        if (s->rk_alloc) {
+            int32_t v = 0;
+            (void)hipStreamSynchronize(s->stream);
+            (void)hipMemcpy(&v, s->d.rk_hist + (which == 8 ? 514 : 515), sizeof(v), hipMemcpyDeviceToHost);
+            (void)hipMemset(s->d.rk_hist + (which == 8 ? 514 : 515), 0, sizeof(v));
+            *out = v;
+        }
+        return GD_OK;
+    }
+#endif
     if (which == 7) {  // 1: the reference-order road selection takes the rank replay (map_obs_rank.hip)
         *out = s->d.rk_on;
         return GD_OK;

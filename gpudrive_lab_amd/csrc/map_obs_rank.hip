@@ -300,8 +300,10 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     const float kmax = d.radius_key_max;
     const float2 *rxy = d.road_xy + r0;
     float key[NG];
-    int nle = 0;
-    float kmax_seen = 0.f;
+    const float t_last = in.t_last;
+    float split = (t_last > 0.f && t_last < 1e30f) ? t_last * 1.5f : 1.f;
+    int nle = 0, nlow = 0;  // candidates inside the radius / below `split` (second count in the upper half)
+    float kmax_seen = 0.f, kmin_seen = __builtin_inff();
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         key[g] = 0.f;
@@ -309,29 +311,40 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             const float2 xy = rxy[ci[g]];
             key[g] = ego_dist2(ex, ey, iw, iz, xy.x, xy.y);
             const bool on = g * 64 + lane < nin;
-            nle += (on && key[g] <= kmax) ? 1 : 0;
+            nle += ((on & (key[g] <= kmax)) ? 1 : 0) + ((on & (key[g] < split)) ? 1 << 16 : 0);
             kmax_seen = fmaxf(kmax_seen, on ? key[g] : 0.f);
+            kmin_seen = fminf(kmin_seen, on ? key[g] : __builtin_inff());
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         nle += __shfl_xor(nle, off);
         kmax_seen = fmaxf(kmax_seen, __shfl_xor(kmax_seen, off));
+        kmin_seen = fminf(kmin_seen, __shfl_xor(kmin_seen, off));
     }
-    const float t_last = in.t_last;
+    nlow = nle >> 16;
+    nle &= 0xffff;
     if (GD_DIAG_IS(d.rk_dbg, 2)) return;
 
     // ---- ranks.  Counting sort into NB buckets (a monotone function of the key: linear up to 1.5 x the previous
     // K-th key, where most candidates lie, logarithmic beyond), then the exact order inside each bucket ----
     for (int b = lane; b < NB / 2; b += 64) L.cnt2[b] = 0u;
     wave_sync();
-    const float split = (t_last > 0.f && t_last < 1e30f) ? t_last * 1.5f : 1.f;
-    const float lin_scale = (float)NLIN / split;
+    // The previous K-th key says where the candidates are dense only while the agent is near where it was recorded.  After
+    // a jump — fewer than a quarter of the candidates below `split` (all of them in a band far above it), or every one
+    // below it (a logged agent back from the padding position, src/sim.cpp:333-343, with checkpoints recorded out there:
+    // the whole world in bucket 0) — the buckets are linear between the smallest and the largest key instead: any
+    // monotone function gives the same ranks, a poor one makes the order inside a bucket quadratic.
+    const bool jumped = nlow * 4 < nin || nlow == nin;  // wave-uniform
+    const float lin_lo = jumped ? kmin_seen : 0.f;
+    const int nlin = jumped ? NB : NLIN;
+    const float lin_scale = jumped ? (float)NB / fmaxf(kmax_seen - kmin_seen, 1e-30f) : (float)NLIN / split;
+    if (jumped) split = __builtin_inff();
     const unsigned int split_bits = __float_as_uint(split);
     // above `split` the buckets are uniform in the key's bit pattern (i.e. logarithmic) up to the largest candidate key
     const float log_scale = (float)(NB - NLIN) / (float)(max(__float_as_uint(kmax_seen), split_bits + 1u) - split_bits + 1u);
     auto bucket_of = [&](float k) -> int {
-        if (k < split) return min(NLIN - 1, max(0, (int)(k * lin_scale)));
+        if (k < split) return min(nlin - 1, max(0, (int)((k - lin_lo) * lin_scale)));
         return NLIN + min(NB - NLIN - 1, (int)((float)(__float_as_uint(k) - split_bits) * log_scale));
     };
     // (the bucket rides in the upper half of the road-index register: registers decide how many waves a SIMD holds)
@@ -414,6 +427,9 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off));
         if (GD_DIAG_IS(d.rk_dbg, 7)) longest = 0;
+#ifdef GD_DIAG
+        if (lane == 0) atomicMax(&d.rk_hist[514], longest);  // diagnostic: the most crowded bucket of this selection
+#endif
         for (int j = M; j < longest; j++) {
             float mkk[U];
             int mpp[U];
@@ -483,7 +499,16 @@ __global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 
     RankIn cur = rank_fetch<A_T>(d, blockIdx.x, threadIdx.x);
     for (int li = blockIdx.x; li < d.live_count; li += gridDim.x) {
         const RankIn nxt = rank_fetch<A_T>(d, li + gridDim.x, threadIdx.x);
+#ifdef GD_DIAG
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
         rank_agent<A_T>(d, cur, threadIdx.x, L);
+#ifdef GD_DIAG
+        if (threadIdx.x == 0) {  // diagnostic: the slowest agent of this selection (cycles / 64)
+            const int c = (int)min((__builtin_amdgcn_s_memtime() - t0) >> 6, 0x7fffffffull);
+            atomicMax(&d.rk_hist[515], c);
+        }
+#endif
         wave_sync();  // the LDS buffers change hands
         cur = nxt;
     }

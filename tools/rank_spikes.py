@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""developer tool (diagnostic build: tools/build_expt.sh diag -DGD_DIAG): per step of the 4096-world config, the road
+observation's time next to the most crowded ranking bucket and the slowest agent of k_knn_rank."""
+import os, sys, time
+os.environ.setdefault("GPUDRIVE_MAX_AGENTS", "64")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["GPUDRIVE_AMD_LIB"] = os.path.join(ROOT, "gpudrive_lab_amd", "expt_diag.so")
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+WL = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+W = 4096 if WL == "cfg3" else 1024
+dev = torch.device("cuda", 0)
+with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+    sim = bench.make_sim(bench.scenes_for(WL, W, 0), bench.params_for(WL), 64, 0)
+    batches = bench.action_batches(W, 64, dev, seed=1234)
+    act = sim.action_tensor().to_torch()
+    sim.kernel_timing(True)
+    for k in range(50):
+        act.copy_(batches[k % 8]); sim.step()
+        torch.cuda.synchronize()
+        ms, n = sim.kernel_timing_read(1)
+        sim.kernel_timing(True)
+        path = sim.debug_road_path()
+        print("step %2d road obs %.0f us  widest bucket %d  slowest agent %.0f kcycles  ranked %d fallback %d far %d max n %d" %
+              (k + 1, 1e3 * ms / max(n, 1), sim.stat(8), sim.stat(9) * 64 / 1e3, (path > 0).sum(), ((path == -1) | (path <= -10)).sum(),
+               (path == -3).sum(), path.max()))
+    sim.close()
