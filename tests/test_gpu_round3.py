@@ -40,7 +40,7 @@ def _bits(t):
     return RC.as_np(t).view(np.uint32)
 
 
-@pytest.mark.parametrize("which", ["bench", "waymo", "waymo_unreduced", "equal_keys"])
+@pytest.mark.parametrize("which", ["bench", "waymo", "waymo_agent_stop", "waymo_unreduced", "equal_keys"])
 def test_rank_replay_equals_history_replay_bit_for_bit(bench_scenes, tmp_path, monkeypatch, which):
     """Two engines on the same scenes and actions, free running: one selects the roads with the rank replay, the other
     with GPUDRIVE_NO_RANK_REPLAY=1 (k_map_obs alone, round 2's kernel).  agent_roadmap_tensor must be bit-identical at
@@ -51,6 +51,11 @@ def test_rank_replay_equals_history_replay_bit_for_bit(bench_scenes, tmp_path, m
         scenes, kw = bench_scenes[:3], BENCH
     elif which == "waymo":
         scenes, kw = [TEST_JSON, SCENE_407, SCENE_4], CLASSIC   # a few hundred roads per world: every road may be a candidate
+    elif which == "waymo_agent_stop":
+        # BASELINE configs[2]'s rules.  Agents come back from the padding position with checkpoints that were recorded out
+        # there (every road a candidate, all of them far below the recorded K-th key): the ranking's buckets then go by
+        # the smallest and largest key (k_knn_rank, `jumped`)
+        scenes, kw = [TEST_JSON, SCENE_407, SCENE_4], dict(CLASSIC, collisionBehaviour=0)
     elif which == "waymo_unreduced":
         # thousands of roads with repeated points (equal keys) and more inserts than the candidate buffer holds for many
         # agents: most groups take the fallback, all of it must still be bit-identical
