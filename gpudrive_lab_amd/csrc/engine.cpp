@@ -144,7 +144,7 @@ struct gd_sim {
         d.cp_hdr = alloc_internal<float4>(2 * WA);
         d.rk_words = alloc_internal<uint32_t>(WA * GD_RANK_NCH);
         d.rk_tl = alloc_internal<float>(WA);
-        d.rk_hist = alloc_internal<int32_t>(516);
+        d.rk_hist = alloc_internal<int32_t>(528);
         d.rk_ticket = alloc_internal<int32_t>(WA);
         d.rk_order = alloc_internal<int32_t>(WA);
         d.road_bbox = alloc_internal<float4>(W);
@@ -1106,19 +1106,20 @@ int gd_attach_bev(gd_sim *s, float *bev) {
 
 int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
 #ifdef GD_DIAG
-    constexpr int32_t kLastStat = 9;
+    constexpr int32_t kLastStat = 17;
 #else
     constexpr int32_t kLastStat = 7;
 #endif
     if (!s || !out || which < 0 || which > kLastStat) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
 #ifdef GD_DIAG
-    if (which == 8 || which == 9) {  // diagnostic build: most crowded ranking bucket / slowest agent (cycles / 64) since last read
+    if (which >= 8) {  // diagnostic build (GPUDRIVE_RANK_DBG=9): 8 = most crowded ranking bucket, 10..17 = clock ticks / 256 per
+                       // phase of k_knn_rank summed over its waves; since the last read
         *out = 0;
         if (s->rk_alloc) {
             int32_t v = 0;
             (void)hipStreamSynchronize(s->stream);
-            (void)hipMemcpy(&v, s->d.rk_hist + (which == 8 ? 514 : 515), sizeof(v), hipMemcpyDeviceToHost);
-            (void)hipMemset(s->d.rk_hist + (which == 8 ? 514 : 515), 0, sizeof(v));
+            (void)hipMemcpy(&v, s->d.rk_hist + 514 + (which - 8), sizeof(v), hipMemcpyDeviceToHost);
+            (void)hipMemset(s->d.rk_hist + 514 + (which - 8), 0, sizeof(v));
             *out = v;
         }
         return GD_OK;
@@ -1199,7 +1200,8 @@ int gd_debug_road_path(gd_sim *s, int32_t *out) {
         HIP_CHECK(hipMemcpy(why.data(), s->d.rk_ticket, WA * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < WA; i++) {
             if (out[i] > 0) out[i] = out[i] == (1 << 30) ? -3 : (out[i] & 0xffff);
-            else if (out[i] == -1 && why[i] < -1) out[i] = -10 + (why[i] + 2);  // -10 no checkpoints / small world, -11 overflow, -12 ties, -13 bypass
+            else if (out[i] == -1 && why[i] < -1) out[i] = -10 + (why[i] + 2);  // -10 no checkpoints / small world, -11 overflow, -13 bypass
+            else if (out[i] == -1 && why[i] >= 0 && ((why[i] >> 30) & 1)) out[i] = -12;  // more than 32 candidates with one key
         }
     });
 }

@@ -108,8 +108,8 @@ struct DevSim {
     uint16_t *rk_spc;      // [W][A][CAP] sorted slot -> road index
     uint32_t *rk_heap;     // [W][A][GD_RANK_HEAP_DW] the replayed heap array as rank pairs
     uint16_t *rk_cpe;      // [W][A][NCP] rank on top of the heap at every checkpoint of this selection
-    int32_t *rk_hist;      // [514] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path, selections so far
-    int32_t *rk_ticket;    // [W][A] bin << 20 | place inside the bin; -1 = not on the rank path this step
+    int32_t *rk_hist;      // [528] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path, selections so far; [514..523] counters of -DGD_DIAG builds
+    int32_t *rk_ticket;    // [W][A] bin << 20 | place inside the bin (bit 30: fell back after taking it); -1 = not on the rank path this step; < -1: why
     int32_t *rk_order;     // [W][A] agents on the rank path, most candidates first
     uint32_t *rk_words;    // [W][A][NCH] candidate bits of 32 roads, one row per agent (k_knn_scan -> k_knn_rank)
     float *rk_tl;          // [W][A] the last K-th key of the checkpoint set in use (scales the ranking buckets)

@@ -49,6 +49,7 @@ constexpr int NLIN = 768;          // of which linear in the key (up to 1.5 x th
 static_assert(K + (NCP - 1) * TILE >= CAP, "a checkpoint slot for every tile of candidates");
 static_assert(CAP % 64 == 0 && NB % 128 == 0 && CAP < 2047, "geometry; less + 1 fits 11 bits");
 constexpr int RK_FAR = 1 << 30;    // rk_n: no road of the world can be within the agent's radius
+constexpr int RK_TIES = 1 << 30;   // rk_ticket: the agent took its place in the replay order, then fell back (equal keys)
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -66,6 +67,24 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
+
+// Wave-wide max / min / sum on the same DPP steps (lane 63 of the inclusive scan, broadcast): a `__shfl_xor` butterfly is six
+// dependent LDS-crossbar round trips, this is six vector instructions and a readlane.  Lanes without a source keep their own
+// value, which is neutral for max and min.
+#define GD_DPP_SELF(v, ctrl, rows) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rows), 0xf, false)
+__device__ __forceinline__ int wave_max(int v) {
+    v = max(v, GD_DPP_SELF(v, 0x111, 0xf));
+    v = max(v, GD_DPP_SELF(v, 0x112, 0xf));
+    v = max(v, GD_DPP_SELF(v, 0x114, 0xf));
+    v = max(v, GD_DPP_SELF(v, 0x118, 0xf));
+    v = max(v, GD_DPP_SELF(v, 0x142, 0xa));
+    v = max(v, GD_DPP_SELF(v, 0x143, 0xc));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// (non-negative floats order like their bit patterns)
+__device__ __forceinline__ float wave_max_nonneg(float f) { return __int_as_float(wave_max(__float_as_int(f))); }
+__device__ __forceinline__ float wave_min_nonneg(float f) { return __int_as_float(~wave_max(~__float_as_int(f))); }
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
 
 // key comparison on ranks: key(a) < key(b)  <=>  (a >> 5) < (b >> 5)  <=>  (a | 31) < b.  0 is "below everything".
 __device__ __forceinline__ bool rank_lt(unsigned int a, unsigned int b) { return (a | 31u) < b; }
@@ -253,8 +272,25 @@ __device__ __forceinline__ RankIn rank_fetch(const DevSim &d, int li, int lane) 
     return in;
 }
 
+#ifdef GD_DIAG
+// diagnostic builds with GPUDRIVE_RANK_DBG=9: clock ticks per phase of the ranking, summed per wave (gd_stat 10..17)
+struct PhaseClock {
+    unsigned long long prev, sum[8];
+    bool on;
+    __device__ __forceinline__ void mark(int n) {
+        if (!on) return;
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        sum[n] += t - prev;
+        prev = t;
+    }
+};
+#define GD_PHASE(n) clk.mark(n)
+#else
+struct PhaseClock {};
+#define GD_PHASE(n)
+#endif
 template <int A_T>
-__device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds &L) {
+__device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds &L, PhaseClock &clk) {
     if (in.state != 1) return;  // fallback or too far from every road (k_knn_scan)
     const int i = in.i, r0 = in.r0, R = in.R;
     const int group = i / 32;  // 32 consecutive agent slots of a world: the fallback unit (a workgroup of k_map_obs)
@@ -287,7 +323,20 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         return;
     }
     wave_sync();
+    // the agent's place in the replay order (k_knn_bins / k_knn_order: most candidates first).  Taken now: the counter's
+    // answer is a trip to the L2 and back that nothing has to wait for until the agent is done
+    const int bin = 255 - min(255, (nin - K) / 5);
+    int ticket = 0;
+    if (lane == 0) ticket = bin << 20 | atomicAdd(&d.rk_hist[bin], 1);
+    GD_PHASE(1);
     if (GD_DIAG_IS(d.rk_dbg, 1)) return;
+    // where this selection's checkpoints start to apply (their K-th distances are filled in by k_knn_finish): checkpoint 0
+    // is the heap of the first K roads (road indices below K are candidates regardless), checkpoint q the heap after
+    // candidate K + 32 q - 1, which holds for every road behind that candidate; rounded up to whole 32-road chunks of the scan
+    if (lane <= (nin - K) / TILE) {
+        const int road = (int)L.cidx[K - 1 + TILE * lane];
+        d.cp_road[(size_t)i * NCP + lane] = (unsigned short)(lane ? min(65535, (road + 1 + 31) & ~31) : (K / 32) * 32);
+    }
     int ci[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) {
@@ -316,14 +365,12 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             kmin_seen = fminf(kmin_seen, on ? key[g] : __builtin_inff());
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        nle += __shfl_xor(nle, off);
-        kmax_seen = fmaxf(kmax_seen, __shfl_xor(kmax_seen, off));
-        kmin_seen = fminf(kmin_seen, __shfl_xor(kmin_seen, off));
-    }
+    nle = wave_sum(nle);
+    kmax_seen = wave_max_nonneg(kmax_seen);  // keys are sums of squares
+    kmin_seen = wave_min_nonneg(kmin_seen);
     nlow = nle >> 16;
     nle &= 0xffff;
+    GD_PHASE(2);
     if (GD_DIAG_IS(d.rk_dbg, 2)) return;
 
     // ---- ranks.  Counting sort into NB buckets (a monotone function of the key: linear up to 1.5 x the previous
@@ -374,6 +421,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
     }
     wave_sync();
+    GD_PHASE(3);
     if (GD_DIAG_IS(d.rk_dbg, 3)) return;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
@@ -385,88 +433,104 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
     }
     wave_sync();
+    GD_PHASE(4);
     if (GD_DIAG_IS(d.rk_dbg, 4)) return;
     const unsigned short *cur16 = reinterpret_cast<const unsigned short *>(L.cnt2);  // cursor of bucket b = its END
-    int too_many_ties = 0, any_tie = 0;
+    // Candidates with a smaller key = those of the earlier buckets + the smaller ones of the own bucket.  The pass is a chain
+    // of LDS round trips with little to issue in between, so it reads generously: the first eight members of every bucket at
+    // once (most hold one or two), then four more per trip while any lane's bucket has members left.  Only keys are read;
+    // candidates that met their own key more than once (equal keys, rare) get their place among those afterwards.
     unsigned int e[NG];
-    constexpr int U = 4, M = 4;
+    unsigned int eqmask = 0u;  // bit g: candidate g of this lane shares its key with another candidate
+    constexpr int U = 4, M = 8, STEP = 4;
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += U) {
         if (g0 * 64 >= nin) break;  // wave-uniform
-        int s0[U], s1[U], less[U], tie[U], longest = 0;
+        int s0[U], s1[U], less[U], eq[U], longest = 0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int b = ci[g0 + u] >> 16;
             s0[u] = b ? (int)cur16[b - 1] : 0;
             s1[u] = (g0 + u) * 64 + lane < nin ? (int)cur16[b] : s0[u];
         }
-        // the first four members of every bucket at once (most buckets hold fewer), the rest in a loop
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int p = (g0 + u) * 64 + lane;
             float mk[M];
-            int mp[M];
 #pragma unroll
-            for (int j = 0; j < M; j++) {
-                const int m = min(s0[u] + j, CAP - 1);
-                mk[j] = L.s.skey[m];
-                mp[j] = L.s.spos[m];
-            }
+            for (int k = 0; k < M; k++) mk[k] = L.s.skey[min(s0[u] + k, CAP - 1)];
             less[u] = s0[u];
-            tie[u] = 0;
+            eq[u] = 0;
             longest = max(longest, s1[u] - s0[u]);
 #pragma unroll
-            for (int j = 0; j < M; j++) {
+            for (int k = 0; k < M; k++) {
                 // bit operations, not &&: the short-circuit form compiles into a branch per term
-                const int inb = s0[u] + j < s1[u] ? 1 : 0;
-                less[u] += inb & (mk[j] < key[g0 + u] ? 1 : 0);
-                tie[u] += inb & (mk[j] == key[g0 + u] ? 1 : 0) & (mp[j] < p ? 1 : 0);
+                const int inb = s0[u] + k < s1[u] ? 1 : 0;
+                less[u] += inb & (mk[k] < key[g0 + u] ? 1 : 0);
+                eq[u] += inb & (mk[k] == key[g0 + u] ? 1 : 0);
             }
         }
-        // larger buckets: the four candidates advance together (one LDS round trip per step, not four)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off));
+        longest = wave_max(longest);
         if (GD_DIAG_IS(d.rk_dbg, 7)) longest = 0;
 #ifdef GD_DIAG
-        if (lane == 0) atomicMax(&d.rk_hist[514], longest);  // diagnostic: the most crowded bucket of this selection
+        if (lane == 0 && d.rk_dbg == 9) atomicMax(&d.rk_hist[514], longest);  // diagnostic: the most crowded bucket of this selection
 #endif
-        for (int j = M; j < longest; j++) {
-            float mkk[U];
-            int mpp[U];
+        for (int j = M; j < longest; j += STEP) {
+            float mkk[U][STEP];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int m = min(s0[u] + j, CAP - 1);
-                mkk[u] = L.s.skey[m];
-                mpp[u] = L.s.spos[m];
-            }
+            for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int inb = s0[u] + j < s1[u] ? 1 : 0;
-                less[u] += inb & (mkk[u] < key[g0 + u] ? 1 : 0);
-                tie[u] += inb & (mkk[u] == key[g0 + u] ? 1 : 0) & (mpp[u] < (g0 + u) * 64 + lane ? 1 : 0);
-            }
+                for (int k = 0; k < STEP; k++) mkk[u][k] = L.s.skey[min(s0[u] + j + k, CAP - 1)];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int k = 0; k < STEP; k++) {
+                    const int inb = s0[u] + j + k < s1[u] ? 1 : 0;
+                    less[u] += inb & (mkk[u][k] < key[g0 + u] ? 1 : 0);
+                    eq[u] += inb & (mkk[u][k] == key[g0 + u] ? 1 : 0);
+                }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            too_many_ties |= ((g0 + u) * 64 + lane < nin && tie[u] > 31) ? 1 : 0;
-            any_tie |= (g0 + u) * 64 + lane < nin ? tie[u] : 0;
-            e[g0 + u] = (unsigned int)(((less[u] + 1) << 5) | (tie[u] & 31));
+            eqmask |= eq[u] > 1 ? 1u << (g0 + u) : 0u;  // (a candidate meets itself once)
+            e[g0 + u] = (unsigned int)((less[u] + 1) << 5);
+        }
+    }
+    int too_many_ties = 0;
+    const bool has_tie = __ballot(eqmask != 0u) != 0ull;  // the replay then compares ranks without their tie field
+    if (has_tie) {
+        // place among the candidates with the same key: those of them that come earlier in road order.  A rolled loop (the
+        // register arrays are picked apart with selects on the wave-uniform g): twenty copies of it cost the common path
+        // its registers
+#pragma clang loop unroll(disable)
+        for (int g = 0; g * 64 < nin; g++) {
+            if (__ballot((eqmask >> g) & 1u) == 0ull) continue;  // wave-uniform
+            int cg = 0;
+#pragma unroll
+            for (int k = 0; k < NG; k++) cg = k == g ? ci[k] : cg;
+            int tie = 0;
+            if ((eqmask >> g) & 1u) {
+                const int b = cg >> 16, p = g * 64 + lane;
+                const int first = b ? (int)cur16[b - 1] : 0, end = (int)cur16[b];
+                float kg = 0.f;  // the candidate's key, from its own entry of the bucket (the key registers are long gone)
+                for (int m = first; m < end; m++) kg = (int)L.s.spos[m] == p ? L.s.skey[m] : kg;
+                for (int m = first; m < end; m++) tie += (L.s.skey[m] == kg ? 1 : 0) & ((int)L.s.spos[m] < p ? 1 : 0);
+            }
+            too_many_ties |= tie > 31 ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < NG; k++) e[k] |= k == g ? (unsigned int)(tie & 31) : 0u;
         }
     }
     wave_sync();  // every read of the sorted arrays is done: their space becomes the slot -> road table
+    GD_PHASE(5);
     if (GD_DIAG_IS(d.rk_dbg, 5)) return;
     if (__ballot(too_many_ties != 0) != 0ull) {
         if (lane == 0) {
             d.rk_n[i] = 0;
-            d.rk_ticket[i] = -4;  // more than 32 candidates with one key
+            d.rk_ticket[i] = ticket | RK_TIES;  // more than 32 candidates with one key (the place in the order stays taken)
             d.rk_fallback[group] = 1;
         }
         return;
     }
-    // where this selection's checkpoints start to apply (their K-th distances are filled in by k_knn_finish):
-    // checkpoint 0 is the heap of the first K roads (road indices below K are candidates regardless), checkpoint q
-    // the heap after candidate K + 32 q - 1, which holds for every road behind that candidate; rounded up to whole
-    // 32-road chunks of the scan
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const int p = g * 64 + lane;
@@ -474,20 +538,18 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             d.rk_E[(size_t)i * CAP + p] = (unsigned short)e[g];
             const int road = ci[g] & 0xffff;
             L.spc[(int)(e[g] >> 5) - 1 + (int)(e[g] & 31u)] = (unsigned short)road;
-            const int t = p - K + 1;  // candidates beyond the first K up to and including this one
-            if (t > 0 && (t & (TILE - 1)) == 0)
-                d.cp_road[(size_t)i * NCP + t / TILE] = (unsigned short)min(65535, (road + 1 + 31) & ~31);
         }
     }
-    if (lane == 0) d.cp_road[(size_t)i * NCP] = (unsigned short)((K / 32) * 32);
     wave_sync();
-    for (int s = lane; s < nin; s += 64) d.rk_spc[(size_t)i * CAP + s] = L.spc[s];
-    const bool has_tie = __ballot(any_tie != 0) != 0ull;  // the replay then compares ranks without their tie field
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (g * 64 < nin && g * 64 + lane < nin) d.rk_spc[(size_t)i * CAP + g * 64 + lane] = L.spc[g * 64 + lane];
+    }
     if (lane == 0) {
         d.rk_n[i] = nin | (nle << 16) | (has_tie ? 1 << 28 : 0);
-        const int bin = 255 - min(255, (nin - K) / 5);  // longest first
-        d.rk_ticket[i] = bin << 20 | atomicAdd(&d.rk_hist[bin], 1);
+        d.rk_ticket[i] = ticket;
     }
+    GD_PHASE(6);
 }
 
 // A wave ranks several agents in turn: tens of thousands of one-agent workgroups cost more in workgroup launches (each is
@@ -497,21 +559,23 @@ __global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 
     if (d.gate_any && *d.any_reset == 0) return;
     __shared__ RankLds L;
     RankIn cur = rank_fetch<A_T>(d, blockIdx.x, threadIdx.x);
+    PhaseClock clk;
+#ifdef GD_DIAG
+    clk.on = d.rk_dbg == 9;
+    for (int k = 0; k < 8; k++) clk.sum[k] = 0ull;
+    clk.prev = __builtin_amdgcn_s_memtime();
+#endif
     for (int li = blockIdx.x; li < d.live_count; li += gridDim.x) {
         const RankIn nxt = rank_fetch<A_T>(d, li + gridDim.x, threadIdx.x);
-#ifdef GD_DIAG
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-#endif
-        rank_agent<A_T>(d, cur, threadIdx.x, L);
-#ifdef GD_DIAG
-        if (threadIdx.x == 0) {  // diagnostic: the slowest agent of this selection (cycles / 64)
-            const int c = (int)min((__builtin_amdgcn_s_memtime() - t0) >> 6, 0x7fffffffull);
-            atomicMax(&d.rk_hist[515], c);
-        }
-#endif
+        GD_PHASE(0);  // between agents: the next agent's fetches are issued, the buffers change hands
+        rank_agent<A_T>(d, cur, threadIdx.x, L, clk);
         wave_sync();  // the LDS buffers change hands
         cur = nxt;
     }
+#ifdef GD_DIAG
+    if (clk.on && threadIdx.x == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(reinterpret_cast<unsigned int *>(&d.rk_hist[516 + k]), (unsigned int)(clk.sum[k] >> 8));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -560,7 +624,7 @@ __global__ __launch_bounds__(256) void k_knn_order(DevSim d) {
     const int i = d.live_list[t];
     const int ticket = d.rk_ticket[i];
     if (ticket < 0) return;  // not on the rank path
-    d.rk_order[d.rk_hist[256 + (ticket >> 20)] + (ticket & 0xfffff)] = i;
+    d.rk_order[d.rk_hist[256 + ((ticket >> 20) & 255)] + (ticket & 0xfffff)] = i;
 }
 
 __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {

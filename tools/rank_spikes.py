@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """developer tool (diagnostic build: tools/build_expt.sh diag -DGD_DIAG): per step of the 4096-world config, the road
-observation's time next to the most crowded ranking bucket and the slowest agent of k_knn_rank."""
+observation's time next to the most crowded ranking bucket of k_knn_rank and how its phases share the waves' time."""
 import os, sys, time
 os.environ.setdefault("GPUDRIVE_MAX_AGENTS", "64")
+os.environ["GPUDRIVE_RANK_DBG"] = "9"  # switches the counters on
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["GPUDRIVE_AMD_LIB"] = os.path.join(ROOT, "gpudrive_lab_amd", "expt_diag.so")
 sys.path.insert(0, ROOT)
@@ -22,7 +23,9 @@ with torch.cuda.stream(torch.cuda.Stream(device=dev)):
         ms, n = sim.kernel_timing_read(1)
         sim.kernel_timing(True)
         path = sim.debug_road_path()
-        print("step %2d road obs %.0f us  widest bucket %d  slowest agent %.0f kcycles  ranked %d fallback %d far %d max n %d" %
-              (k + 1, 1e3 * ms / max(n, 1), sim.stat(8), sim.stat(9) * 64 / 1e3, (path > 0).sum(), ((path == -1) | (path <= -10)).sum(),
-               (path == -3).sum(), path.max()))
+        ph = np.array([sim.stat(10 + q) for q in range(7)], np.float64)
+        print("step %2d road obs %.0f us  widest bucket %d  ranked %d fallback %d far %d max n %d  k_knn_rank phases %% (between agents, words, keys, "
+              "count+prefix, scatter, order in buckets, write-out): %s" %
+              (k + 1, 1e3 * ms / max(n, 1), sim.stat(8), (path > 0).sum(), ((path == -1) | (path <= -10)).sum(),
+               (path == -3).sum(), path.max(), np.round(100 * ph / max(ph.sum(), 1), 1)))
     sim.close()
