@@ -251,17 +251,24 @@ struct RankIn {
     float ex, ey, iw, iz, t_last;
     unsigned int wd[WPL];
 };
+// A value at a wave-uniform address that this kernel does not change, read through the scalar cache.  As vector loads the
+// chain list -> agent -> state / pose waited, at each link, for every store the wave had issued for the previous agent
+// (vector memory operations are counted in order): a fifth of the kernel.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
 template <int A_T>
 __device__ __forceinline__ RankIn rank_fetch(const DevSim &d, int li, int lane) {
     RankIn in;
-    in.i = li < d.live_count ? d.live_list[li] : 0;
-    in.state = li < d.live_count ? d.rk_n[in.i] : 0;
+    in.i = li < d.live_count ? uniform_load(d.live_list + li) : 0;
+    in.state = li < d.live_count ? uniform_load(d.rk_n + in.i) : 0;  // (k_knn_scan's; this kernel rewrites it once the agent is ranked)
     const int w = in.i / A_T;
-    in.r0 = d.road_off[w];
-    in.R = d.road_off[w + 1] - in.r0;
-    in.ex = d.px[in.i]; in.ey = d.py[in.i];
-    in.iw = d.qw[in.i]; in.iz = -d.qz[in.i];  // the INVERSE rotation
-    in.t_last = d.rk_tl[in.i];
+    in.r0 = uniform_load(d.road_off + w);
+    in.R = uniform_load(d.road_off + w + 1) - in.r0;
+    in.ex = uniform_load(d.px + in.i); in.ey = uniform_load(d.py + in.i);
+    in.iw = uniform_load(d.qw + in.i); in.iz = -uniform_load(d.qz + in.i);  // the INVERSE rotation
+    in.t_last = uniform_load(d.rk_tl + in.i);
     const int nch = (in.R + 31) >> 5;
     const uint32_t *words = d.rk_words + (size_t)in.i * GD_RANK_NCH;  // agent-major: one coalesced read
 #pragma unroll
@@ -272,14 +279,13 @@ __device__ __forceinline__ RankIn rank_fetch(const DevSim &d, int li, int lane) 
     return in;
 }
 
-#ifdef GD_DIAG
-// diagnostic builds with GPUDRIVE_RANK_DBG=9: clock ticks per phase of the ranking, summed per wave (gd_stat 10..17)
+#ifdef GD_CLOCKS
+// builds with -DGD_CLOCKS (tools/build_expt.sh clk -DGD_CLOCKS; nothing else differs from the product code): clock ticks per
+// phase of the ranking, summed per wave in scalar registers, added up over the waves (gd_stat 10..17)
 struct PhaseClock {
-    unsigned long long prev, sum[8];
-    bool on;
+    unsigned int prev, sum[8];
     __device__ __forceinline__ void mark(int n) {
-        if (!on) return;
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        const unsigned int t = (unsigned int)__builtin_amdgcn_s_memtime();
         sum[n] += t - prev;
         prev = t;
     }
@@ -291,8 +297,12 @@ struct PhaseClock {};
 #endif
 template <int A_T>
 __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds &L, PhaseClock &clk) {
-    if (in.state != 1) return;  // fallback or too far from every road (k_knn_scan)
-    const int i = in.i, r0 = in.r0, R = in.R;
+    if (__builtin_amdgcn_readfirstlane(in.state) != 1) return;  // fallback or too far from every road (k_knn_scan)
+    // every lane fetched the same values: as scalars they index through scalar base addresses (a per-lane 64-bit pointer per
+    // array costs two registers each, and reloading a spilled one made the wave wait for all its outstanding stores)
+    auto uni = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
+    auto unif = [](float v) -> float { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const int i = uni(in.i), r0 = uni(in.r0), R = uni(in.R);
     const int group = i / 32;  // 32 consecutive agent slots of a world: the fallback unit (a workgroup of k_map_obs)
     constexpr int NG = CAP / 64;  // candidates per lane
 
@@ -337,32 +347,55 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         const int road = (int)L.cidx[K - 1 + TILE * lane];
         d.cp_road[(size_t)i * NCP + lane] = (unsigned short)(lane ? min(65535, (road + 1 + 31) & ~31) : (K / 32) * 32);
     }
+    // A lane has 13 candidates on average, 20 at most.  The passes over them go in groups of GQ with one wave-uniform guard
+    // per group and nothing conditional inside (idle lanes work on road 0): a guard per candidate is a branch per candidate,
+    // and the compiler then waits for each load before it issues the next
+    constexpr int GQ = 5;
+    static_assert(NG % GQ == 0, "whole groups");
     int ci[NG];
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        ci[g] = 0;
-        if (g * 64 < nin) ci[g] = g * 64 + lane < nin ? (int)L.cidx[g * 64 + lane] : 0;  // wave-uniform guard: a lane has 13 on average
+    for (int g0 = 0; g0 < NG; g0 += GQ) {
+#pragma unroll
+        for (int u = 0; u < GQ; u++) ci[g0 + u] = 0;
+        if (g0 * 64 < nin) {  // wave-uniform
+            int v[GQ];
+#pragma unroll
+            for (int u = 0; u < GQ; u++) v[u] = (int)L.cidx[(g0 + u) * 64 + lane];  // (beyond nin: stale, dropped below)
+#pragma unroll
+            for (int u = 0; u < GQ; u++) ci[g0 + u] = (g0 + u) * 64 + lane < nin ? v[u] : 0;
+        }
     }
     wave_sync();  // the index buffer becomes the sorted arrays
-    // ---- exact keys (gd_math.hpp ego_dist2: the reference's arithmetic); every gather of the lane is in flight at once ----
-    const float ex = in.ex, ey = in.ey, iw = in.iw, iz = in.iz;
+    // ---- exact keys (gd_math.hpp ego_dist2: the reference's arithmetic); the gathers of a group are in flight together ----
+    const float ex = unif(in.ex), ey = unif(in.ey), iw = unif(in.iw), iz = unif(in.iz);
     const float kmax = d.radius_key_max;
     const float2 *rxy = d.road_xy + r0;
     float key[NG];
-    const float t_last = in.t_last;
+    const float t_last = unif(in.t_last);
     float split = (t_last > 0.f && t_last < 1e30f) ? t_last * 1.5f : 1.f;
     int nle = 0, nlow = 0;  // candidates inside the radius / below `split` (second count in the upper half)
     float kmax_seen = 0.f, kmin_seen = __builtin_inff();
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        key[g] = 0.f;
-        if (g * 64 < nin) {  // wave-uniform
-            const float2 xy = rxy[ci[g]];
-            key[g] = ego_dist2(ex, ey, iw, iz, xy.x, xy.y);
-            const bool on = g * 64 + lane < nin;
-            nle += ((on & (key[g] <= kmax)) ? 1 : 0) + ((on & (key[g] < split)) ? 1 << 16 : 0);
-            kmax_seen = fmaxf(kmax_seen, on ? key[g] : 0.f);
-            kmin_seen = fminf(kmin_seen, on ? key[g] : __builtin_inff());
+    for (int g0 = 0; g0 < NG; g0 += GQ) {
+#pragma unroll
+        for (int u = 0; u < GQ; u++) key[g0 + u] = 0.f;
+        if (g0 * 64 < nin) {  // wave-uniform
+            float2 xy[GQ];
+#pragma unroll
+            for (int u = 0; u < GQ; u++) xy[u] = rxy[(unsigned int)ci[g0 + u]];
+            // (all five before the first use: left alone, the scheduler pairs each load with its arithmetic to save registers)
+            static_assert(GQ == 5, "operand list");
+            asm volatile("" : "+v"(xy[0].x), "+v"(xy[0].y), "+v"(xy[1].x), "+v"(xy[1].y), "+v"(xy[2].x), "+v"(xy[2].y),
+                              "+v"(xy[3].x), "+v"(xy[3].y), "+v"(xy[4].x), "+v"(xy[4].y));
+#pragma unroll
+            for (int u = 0; u < GQ; u++) {
+                const int g = g0 + u;
+                key[g] = ego_dist2(ex, ey, iw, iz, xy[u].x, xy[u].y);
+                const bool on = g * 64 + lane < nin;
+                nle += ((on & (key[g] <= kmax)) ? 1 : 0) + ((on & (key[g] < split)) ? 1 << 16 : 0);
+                kmax_seen = fmaxf(kmax_seen, on ? key[g] : 0.f);
+                kmin_seen = fminf(kmin_seen, on ? key[g] : __builtin_inff());
+            }
         }
     }
     nle = wave_sum(nle);
@@ -424,12 +457,22 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     GD_PHASE(3);
     if (GD_DIAG_IS(d.rk_dbg, 3)) return;
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        if (g * 64 < nin && g * 64 + lane < nin) {
-            const int b = ci[g] >> 16, sh = (b & 1) * 16;
-            const int sl = (int)((atomicAdd(&L.cnt2[b >> 1], 1u << sh) >> sh) & 0xffffu);  // any order inside the bucket
-            L.s.skey[sl] = key[g];
-            L.s.spos[sl] = (unsigned short)(g * 64 + lane);
+    for (int g0 = 0; g0 < NG; g0 += GQ) {
+        if (g0 * 64 < nin) {  // wave-uniform
+            int sl[GQ];
+#pragma unroll
+            for (int u = 0; u < GQ; u++) {  // any order inside the bucket; idle lanes add nothing (to bucket 0)
+                const int b = ci[g0 + u] >> 16, sh = (b & 1) * 16;
+                const unsigned int one = (g0 + u) * 64 + lane < nin ? 1u << sh : 0u;
+                sl[u] = (int)((atomicAdd(&L.cnt2[b >> 1], one) >> sh) & 0xffffu);
+            }
+#pragma unroll
+            for (int u = 0; u < GQ; u++) {
+                if ((g0 + u) * 64 + lane < nin) {
+                    L.s.skey[sl[u]] = key[g0 + u];
+                    L.s.spos[sl[u]] = (unsigned short)((g0 + u) * 64 + lane);
+                }
+            }
         }
     }
     wave_sync();
@@ -531,19 +574,29 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
         return;
     }
+    // (rows through scalar base addresses and unsigned 32-bit lane offsets: see `uni` above)
+    unsigned short *const E_row = d.rk_E + (size_t)i * CAP, *const spc_row = d.rk_spc + (size_t)i * CAP;
+    const unsigned int ulane = (unsigned int)lane;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        const int p = g * 64 + lane;
-        if (p < nin) {
-            d.rk_E[(size_t)i * CAP + p] = (unsigned short)e[g];
-            const int road = ci[g] & 0xffff;
-            L.spc[(int)(e[g] >> 5) - 1 + (int)(e[g] & 31u)] = (unsigned short)road;
+        if (g * 64 < nin) {  // wave-uniform
+            if (g * 64 + lane < nin) {
+                E_row[g * 64u + ulane] = (unsigned short)e[g];
+                L.spc[(int)(e[g] >> 5) - 1 + (int)(e[g] & 31u)] = (unsigned short)(ci[g] & 0xffff);
+            }
         }
     }
     wave_sync();
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        if (g * 64 < nin && g * 64 + lane < nin) d.rk_spc[(size_t)i * CAP + g * 64 + lane] = L.spc[g * 64 + lane];
+    for (int g0 = 0; g0 < NG; g0 += GQ) {
+        if (g0 * 64 < nin) {  // wave-uniform
+            unsigned short v[GQ];
+#pragma unroll
+            for (int u = 0; u < GQ; u++) v[u] = L.spc[(g0 + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < GQ; u++)
+                if ((g0 + u) * 64 + lane < nin) spc_row[(g0 + u) * 64u + ulane] = v[u];
+        }
     }
     if (lane == 0) {
         d.rk_n[i] = nin | (nle << 16) | (has_tie ? 1 << 28 : 0);
@@ -560,10 +613,9 @@ __global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 
     __shared__ RankLds L;
     RankIn cur = rank_fetch<A_T>(d, blockIdx.x, threadIdx.x);
     PhaseClock clk;
-#ifdef GD_DIAG
-    clk.on = d.rk_dbg == 9;
-    for (int k = 0; k < 8; k++) clk.sum[k] = 0ull;
-    clk.prev = __builtin_amdgcn_s_memtime();
+#ifdef GD_CLOCKS
+    for (int k = 0; k < 8; k++) clk.sum[k] = 0u;
+    clk.prev = (unsigned int)__builtin_amdgcn_s_memtime();
 #endif
     for (int li = blockIdx.x; li < d.live_count; li += gridDim.x) {
         const RankIn nxt = rank_fetch<A_T>(d, li + gridDim.x, threadIdx.x);
@@ -572,9 +624,9 @@ __global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 
         wave_sync();  // the LDS buffers change hands
         cur = nxt;
     }
-#ifdef GD_DIAG
-    if (clk.on && threadIdx.x == 0)
-        for (int k = 0; k < 8; k++) atomicAdd(reinterpret_cast<unsigned int *>(&d.rk_hist[516 + k]), (unsigned int)(clk.sum[k] >> 8));
+#ifdef GD_CLOCKS
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(reinterpret_cast<unsigned int *>(&d.rk_hist[516 + k]), clk.sum[k] >> 8);
 #endif
 }
 

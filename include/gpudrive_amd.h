@@ -215,9 +215,9 @@ int gd_attach_bev(gd_sim *sim, float *bev);
  * 1 = steps launched kernel by kernel, 2 = hipGraph captures; the schedule the engine chose for this batch (it never
  * changes a result): 3 = set-order road kernel stores its rows itself (0 / 1), 4 = its agents per wave, 5 = live agents,
  * 6 = agents per wave of the reference-order road kernel (compile-time GD_MAP_OBS_AW of this build), 7 = the
- * reference-order road selection takes the rank replay (0 / 1).  Builds with -DGD_DIAG (tools/build_expt.sh) add
- * 8 = the most crowded ranking bucket, 10..17 = clock ticks per phase of k_knn_rank, since the last read (with
- * GPUDRIVE_RANK_DBG=9); otherwise GD_ERR_INVALID. */
+ * reference-order road selection takes the rank replay (0 / 1).  Developer builds (tools/build_expt.sh) add 8 = the most
+ * crowded ranking bucket (-DGD_DIAG with GPUDRIVE_RANK_DBG=9) and 10..17 = clock ticks per phase of k_knn_rank
+ * (-DGD_CLOCKS), both since the last read; otherwise GD_ERR_INVALID. */
 int gd_stat(gd_sim *sim, int32_t which, int64_t *out);
 
 /* Timing hooks for the bench: HIP events around the named kernel on the engine's stream (a fixed ring of event pairs,

@@ -5,7 +5,7 @@ import os, sys, time
 os.environ.setdefault("GPUDRIVE_MAX_AGENTS", "64")
 os.environ["GPUDRIVE_RANK_DBG"] = "9"  # switches the counters on
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["GPUDRIVE_AMD_LIB"] = os.path.join(ROOT, "gpudrive_lab_amd", "expt_diag.so")
+os.environ["GPUDRIVE_AMD_LIB"] = os.path.join(ROOT, "gpudrive_lab_amd", "expt_%s.so" % os.environ.get("EXPT", "diag"))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench
@@ -23,9 +23,9 @@ with torch.cuda.stream(torch.cuda.Stream(device=dev)):
         ms, n = sim.kernel_timing_read(1)
         sim.kernel_timing(True)
         path = sim.debug_road_path()
-        ph = np.array([sim.stat(10 + q) for q in range(7)], np.float64)
+        ph = np.array([sim.stat(10 + q) for q in range(7)], np.float64) if os.environ.get('EXPT') == 'clk' else np.zeros(7)
         print("step %2d road obs %.0f us  widest bucket %d  ranked %d fallback %d far %d max n %d  k_knn_rank phases %% (between agents, words, keys, "
               "count+prefix, scatter, order in buckets, write-out): %s" %
-              (k + 1, 1e3 * ms / max(n, 1), sim.stat(8), (path > 0).sum(), ((path == -1) | (path <= -10)).sum(),
+              (k + 1, 1e3 * ms / max(n, 1), sim.stat(8) if os.environ.get('EXPT', 'diag') == 'diag' else -1, (path > 0).sum(), ((path == -1) | (path <= -10)).sum(),
                (path == -3).sum(), path.max(), np.round(100 * ph / max(ph.sum(), 1), 1)))
     sim.close()
