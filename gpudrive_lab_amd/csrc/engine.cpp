@@ -627,6 +627,10 @@ struct gd_sim {
                     if (a < w_agents[w]) live.push_back(w * A + a);
             d.live_count = static_cast<int>(live.size());
             if (!live.empty()) HIP_CHECK(hipMemcpy(d.live_list, live.data(), sizeof(int32_t) * live.size(), hipMemcpyHostToDevice));
+            live.clear();
+            for (int w = 0; w < W; w++)  // world-major: the rank kernel wants neighbours in the list to share their roads
+                for (int a = 0; a < w_agents[w]; a++) live.push_back(w * A + a);
+            if (!live.empty()) HIP_CHECK(hipMemcpy(d.live_wm, live.data(), sizeof(int32_t) * live.size(), hipMemcpyHostToDevice));
             // likewise the set-order road kernel's workgroups (4 waves x set_apw agents each)
             std::vector<int32_t> groups;
             const int per = 4 * d.set_apw;
@@ -922,6 +926,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.gate_any = 0;
         d.road_off = s->alloc_internal<int32_t>(W + 1);
         d.live_list = s->alloc_internal<int32_t>(WA);
+        d.live_wm = s->alloc_internal<int32_t>(WA);
         d.live_count = 0;
         d.set_groups = s->alloc_internal<int32_t>(WA);
         d.set_group_count = 0;

@@ -50,6 +50,7 @@ struct DevSim {
     int knn_order;    // GD_KNN_*
     int set_fused_rows;  // set-order mode: the selection kernel writes the rows itself (several generations of workgroups, ragged batches)
     int32_t *live_list;  // [W * A] world * A + agent of every live agent, agent-major (rebuilt with the worlds)
+    int32_t *live_wm;    // [W * A] the same agents world by world (k_knn_rank: neighbours in the list share their road points)
     int live_count;
     int32_t *set_groups;  // set-order kernel: (world << 8 | group) of every group of 4 * set_apw agent slots that holds a live agent
     int set_group_count;

@@ -261,7 +261,7 @@ __device__ __forceinline__ T uniform_load(const T *p) {
 template <int A_T>
 __device__ __forceinline__ RankIn rank_fetch(const DevSim &d, int li, int lane) {
     RankIn in;
-    in.i = li < d.live_count ? uniform_load(d.live_list + li) : 0;
+    in.i = li < d.live_count ? uniform_load(d.live_wm + li) : 0;
     in.state = li < d.live_count ? uniform_load(d.rk_n + in.i) : 0;  // (k_knn_scan's; this kernel rewrites it once the agent is ranked)
     const int w = in.i / A_T;
     in.r0 = uniform_load(d.road_off + w);
@@ -296,8 +296,14 @@ struct PhaseClock {};
 #define GD_PHASE(n)
 #endif
 template <int A_T>
-__device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds &L, PhaseClock &clk) {
-    if (__builtin_amdgcn_readfirstlane(in.state) != 1) return;  // fallback or too far from every road (k_knn_scan)
+__device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds &L, PhaseClock &clk, int next_entry,
+                                           RankIn &nxt) {
+    // The next agent's inputs are requested in the middle of this one, behind the last gather of the keys: vector memory
+    // operations complete in order, so requested up front they (1.3 KB from HBM) were what every gather then waited for.
+    if (__builtin_amdgcn_readfirstlane(in.state) != 1) {  // fallback or too far from every road (k_knn_scan)
+        nxt = rank_fetch<A_T>(d, next_entry, lane);
+        return;
+    }
     // every lane fetched the same values: as scalars they index through scalar base addresses (a per-lane 64-bit pointer per
     // array costs two registers each, and reloading a spilled one made the wave wait for all its outstanding stores)
     auto uni = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
@@ -307,13 +313,20 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     constexpr int NG = CAP / 64;  // candidates per lane
 
     // ---- candidate words -> road indices in ascending order ----
+    // Roads 0..K-1 are candidates regardless (k_knn_scan sets their bits) and their positions are their indices: written
+    // directly, not bit by bit (the lanes that own those seven words would loop 32 times while the others wait)
     const int nch = (R + 31) >> 5;
-    int nin = 0;
+    static_assert(K == 200 && CAP >= 256, "roads 0..K-1: four stores per lane");
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q * 64 + lane < K) L.cidx[q * 64 + lane] = (unsigned short)(q * 64 + lane);
+    int nin = K;
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
         if (k * 64 >= nch || nin > CAP) break;  // wave-uniform
         const int c = k * 64 + lane;
         unsigned int wd = in.wd[k];
+        if (k == 0) wd = c < K / 32 ? 0u : (c == K / 32 ? wd & ~((1u << (K % 32)) - 1u) : wd);
         const int pc = __popc(wd);
         const int incl = wave_incl_scan(pc);
         int pos = nin + incl - pc;
@@ -322,6 +335,9 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         while (wd) {
             L.cidx[pos++] = (unsigned short)((c << 5) + __ffs(wd) - 1);
             wd &= wd - 1u;
+#ifdef GD_CLOCKS
+            clk.sum[7] += 256u;  // (counts the wave's trips through this loop: gd_stat 17)
+#endif
         }
     }
     if (nin > CAP) {
@@ -330,6 +346,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             d.rk_ticket[i] = -3;  // more candidates than the buffer holds
             d.rk_fallback[group] = 1;
         }
+        nxt = rank_fetch<A_T>(d, next_entry, lane);
         return;
     }
     wave_sync();
@@ -339,7 +356,10 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     int ticket = 0;
     if (lane == 0) ticket = bin << 20 | atomicAdd(&d.rk_hist[bin], 1);
     GD_PHASE(1);
-    if (GD_DIAG_IS(d.rk_dbg, 1)) return;
+    if (GD_DIAG_IS(d.rk_dbg, 1)) {
+        nxt = rank_fetch<A_T>(d, next_entry, lane);
+        return;
+    }
     // where this selection's checkpoints start to apply (their K-th distances are filled in by k_knn_finish): checkpoint 0
     // is the heap of the first K roads (road indices below K are candidates regardless), checkpoint q the heap after
     // candidate K + 32 q - 1, which holds for every road behind that candidate; rounded up to whole 32-road chunks of the scan
@@ -398,6 +418,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             }
         }
     }
+    nxt = rank_fetch<A_T>(d, next_entry, lane);
     nle = wave_sum(nle);
     kmax_seen = wave_max_nonneg(kmax_seen);  // keys are sums of squares
     kmin_seen = wave_min_nonneg(kmin_seen);
@@ -486,6 +507,11 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     unsigned int e[NG];
     unsigned int eqmask = 0u;  // bit g: candidate g of this lane shares its key with another candidate
     constexpr int U = 4, M = 8, STEP = 4;
+    // A read past the end of the own bucket meets keys of later buckets, which are larger (the bucket function is monotone)
+    // and so count neither as smaller nor as equal: no bounds test per member.  Past the last candidate it meets +inf.
+    const int lim = min(nin, CAP - 1);  // (nin == CAP: the clamp re-reads the largest key, which is not smaller than any)
+    if (lane == 0 && nin < CAP) L.s.skey[nin] = __builtin_inff();
+    wave_sync();
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += U) {
         if (g0 * 64 >= nin) break;  // wave-uniform
@@ -500,16 +526,14 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         for (int u = 0; u < U; u++) {
             float mk[M];
 #pragma unroll
-            for (int k = 0; k < M; k++) mk[k] = L.s.skey[min(s0[u] + k, CAP - 1)];
+            for (int k = 0; k < M; k++) mk[k] = L.s.skey[min(s0[u] + k, lim)];
             less[u] = s0[u];
             eq[u] = 0;
             longest = max(longest, s1[u] - s0[u]);
 #pragma unroll
             for (int k = 0; k < M; k++) {
-                // bit operations, not &&: the short-circuit form compiles into a branch per term
-                const int inb = s0[u] + k < s1[u] ? 1 : 0;
-                less[u] += inb & (mk[k] < key[g0 + u] ? 1 : 0);
-                eq[u] += inb & (mk[k] == key[g0 + u] ? 1 : 0);
+                less[u] += mk[k] < key[g0 + u] ? 1 : 0;
+                eq[u] += mk[k] == key[g0 + u] ? 1 : 0;
             }
         }
         longest = wave_max(longest);
@@ -522,19 +546,18 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
-                for (int k = 0; k < STEP; k++) mkk[u][k] = L.s.skey[min(s0[u] + j + k, CAP - 1)];
+                for (int k = 0; k < STEP; k++) mkk[u][k] = L.s.skey[min(s0[u] + j + k, lim)];
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int k = 0; k < STEP; k++) {
-                    const int inb = s0[u] + j + k < s1[u] ? 1 : 0;
-                    less[u] += inb & (mkk[u][k] < key[g0 + u] ? 1 : 0);
-                    eq[u] += inb & (mkk[u][k] == key[g0 + u] ? 1 : 0);
+                    less[u] += mkk[u][k] < key[g0 + u] ? 1 : 0;
+                    eq[u] += mkk[u][k] == key[g0 + u] ? 1 : 0;
                 }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            eqmask |= eq[u] > 1 ? 1u << (g0 + u) : 0u;  // (a candidate meets itself once)
+            eqmask |= (eq[u] > 1) & ((g0 + u) * 64 + lane < nin) ? 1u << (g0 + u) : 0u;  // (a candidate meets itself once)
             e[g0 + u] = (unsigned int)((less[u] + 1) << 5);
         }
     }
@@ -611,16 +634,24 @@ template <int A_T>
 __global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 registers: four waves per SIMD, like the LDS
     if (d.gate_any && *d.any_reset == 0) return;
     __shared__ RankLds L;
-    RankIn cur = rank_fetch<A_T>(d, blockIdx.x, threadIdx.x);
+    // Which agents a wave takes.  The live agents are listed world by world (live_wm); workgroup b runs on XCD b % 8, and a
+    // world's 64-entry chunk of the list goes to the waves of ONE XCD, so that the road points its agents gather (32 KB per
+    // world on the bench scene) are fetched into one L2 instead of eight, and the waves resident at a time work on a few dozen
+    // worlds instead of all of them (in agent-major order every generation of waves touched every world: 32 MB against 4 MB of
+    // L2 per XCD).  The t-th entry of XCD x's sequence is entry t % 64 of chunk (t / 64) * 8 + x.
+    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7;  // (the grid is a multiple of 8 workgroups)
+    auto entry = [&](int t) -> int { return (((t >> 6) * 8 + xcd) << 6) + (t & 63); };
+    int t = blockIdx.x >> 3;
+    RankIn cur = rank_fetch<A_T>(d, entry(t), threadIdx.x);
     PhaseClock clk;
 #ifdef GD_CLOCKS
     for (int k = 0; k < 8; k++) clk.sum[k] = 0u;
     clk.prev = (unsigned int)__builtin_amdgcn_s_memtime();
 #endif
-    for (int li = blockIdx.x; li < d.live_count; li += gridDim.x) {
-        const RankIn nxt = rank_fetch<A_T>(d, li + gridDim.x, threadIdx.x);
-        GD_PHASE(0);  // between agents: the next agent's fetches are issued, the buffers change hands
-        rank_agent<A_T>(d, cur, threadIdx.x, L, clk);
+    for (; entry(t) < d.live_count; t += per_xcd) {  // (entries grow with t: the first one beyond the list ends the wave)
+        RankIn nxt;
+        GD_PHASE(0);  // between agents: the buffers change hands
+        rank_agent<A_T>(d, cur, threadIdx.x, L, clk, entry(t + per_xcd), nxt);
         wave_sync();  // the LDS buffers change hands
         cur = nxt;
     }
@@ -774,18 +805,23 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
         auto med3 = [](unsigned int a, unsigned int b, unsigned int c) -> unsigned int {
             return max(min(a, b), min(max(a, b), c));  // the backend folds this into v_med3_u32
         };
+        // The ranks arrive eight at a time (16 bytes), two blocks ahead.  An outer loop per block: the request for block b + 2
+        // is issued at the top and its registers are not touched for eight rounds (inside one flat loop the compiler copied the
+        // freshly requested block into place at once, i.e. waited a memory round trip every eighth round: a quarter of the kernel)
 #pragma clang loop unroll(disable)
-        for (int p = K; p < nmax; p++) {
+        for (int p0 = K; p0 < nmax; p0 += 8) {
+          uint4 w8 = cur;
+          cur = nxt;
+          nxt = blocks[((p0 - K) >> 3) + 2];  // may run past this agent's candidates: the array ends in slack.  Every lane, idle
+                                              // ones too (they read row 0): a merge with the old value would wait for the data
+#pragma clang loop unroll(disable)
+          for (int p = p0; p < min(p0 + 8, nmax); p++) {
             const int t = p - K;
-            const unsigned int y = cur.x & 0xffffu;
-            cur.x = (cur.x >> 16) | (cur.y << 16);
-            cur.y = (cur.y >> 16) | (cur.z << 16);
-            cur.z = (cur.z >> 16) | (cur.w << 16);
-            cur.w = cur.w >> 16;
-            if ((t & 7) == 7) {
-                cur = nxt;
-                if (on) nxt = blocks[(t >> 3) + 2];  // may run past this agent's candidates: the array ends in slack
-            }
+            const unsigned int y = w8.x & 0xffffu;
+            w8.x = (w8.x >> 16) | (w8.y << 16);
+            w8.y = (w8.y >> 16) | (w8.z << 16);
+            w8.z = (w8.z >> 16) | (w8.w << 16);
+            w8.w = w8.w >> 16;
             if (p < n && lt(y, r[1])) {
                 // pop_heap: the hole goes from the root to the bottom of the (K - 1)-element heap along the larger child.
                 // Levels 0 and 1 are decided in registers (slots 1..7 live there during the replay); below that two levels
@@ -874,6 +910,7 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
                 }
             }
             if (((t + 1) & (TILE - 1)) == 0 && p < n) cpe[(t + 1) / TILE] = (unsigned short)r[1];
+          }
         }
     };
     if (__ballot(on && has_tie) != 0ull) replay(std::true_type{});
@@ -1010,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
 
 void launch_map_obs_rank(const DevSim &d, hipStream_t st) {
     if (d.live_count == 0) return;
-    const dim3 gr(std::min(d.live_count, 256 * 8 * 4)), g4((d.live_count + 3) / 4), gw(d.W * (d.A / 64));  // rank: 8 waves per CU fit (LDS), four rounds of them
+    const dim3 gr(std::min((d.live_count + 7) / 8 * 8, 256 * 8 * 4)), g4((d.live_count + 3) / 4), gw(d.W * (d.A / 64));  // rank: 8 waves per CU fit (LDS), four rounds of them
     if (d.A == 64) {
         hipLaunchKernelGGL((k_knn_scan<64>), gw, dim3(256), 0, st, d);
         hipLaunchKernelGGL((k_knn_rank<64>), gr, dim3(64), 0, st, d);

@@ -28,4 +28,6 @@ with torch.cuda.stream(torch.cuda.Stream(device=dev)):
               "count+prefix, scatter, order in buckets, write-out): %s" %
               (k + 1, 1e3 * ms / max(n, 1), sim.stat(8) if os.environ.get('EXPT', 'diag') == 'diag' else -1, (path > 0).sum(), ((path == -1) | (path <= -10)).sum(),
                (path == -3).sum(), path.max(), np.round(100 * ph / max(ph.sum(), 1), 1)))
+        if os.environ.get('EXPT') == 'clk':
+            print("        trips through the word-expansion loop per ranked agent: %.1f" % (sim.stat(17) / max((path > 0).sum(), 1)))
     sim.close()
