@@ -328,6 +328,9 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         unsigned int wd = in.wd[k];
         if (k == 0) wd = c < K / 32 ? 0u : (c == K / 32 ? wd & ~((1u << (K % 32)) - 1u) : wd);
         const int pc = __popc(wd);
+#ifdef GD_CLOCKS
+        clk.sum[7] += (unsigned int)wave_max(pc) << 8;  // the wave's trips through the loop below (gd_stat 17)
+#endif
         const int incl = wave_incl_scan(pc);
         int pos = nin + incl - pc;
         nin += __builtin_amdgcn_readlane(incl, 63);
@@ -335,9 +338,6 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         while (wd) {
             L.cidx[pos++] = (unsigned short)((c << 5) + __ffs(wd) - 1);
             wd &= wd - 1u;
-#ifdef GD_CLOCKS
-            clk.sum[7] += 256u;  // (counts the wave's trips through this loop: gd_stat 17)
-#endif
         }
     }
     if (nin > CAP) {
