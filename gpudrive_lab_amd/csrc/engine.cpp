@@ -592,15 +592,15 @@ struct gd_sim {
         choose_set_schedule();
         if (rk_possible) {
             // Which worlds take the rank replay (neither path changes a result).  Measured at 64 agent slots (road
-            // observation, ms): 1024 worlds x 4096 roads 1.53 ranked / 1.84 on keys; 1024 Waymo tiles (346-873 roads) 0.58 /
-            // 0.47 -- there k_map_obs is one short generation of workgroups and the rank kernels' fixed costs do not pay;
-            // 4096 Waymo tiles 1.10 / 1.74 -- five generations of k_map_obs workgroups, where the ranked path's occupancy
-            // counts.  So: large worlds always, every world with at least K roads once k_map_obs would need more than three
-            // generations.  GPUDRIVE_RANK_MIN_ROADS pins the threshold.
+            // observation, ms): 1024 worlds x 4096 roads 1.19 ranked / 1.84 on keys; 1024 Waymo tiles (346-873 roads) 0.44 /
+            // 0.47; 4096 Waymo tiles 0.94 / 1.74.  The rank kernels' fixed costs (seven launches, a replay as long as the
+            // longest agent's candidate list) pay once k_map_obs's workgroups fill the chip: large worlds always, every
+            // world with at least K roads from one full generation of k_map_obs workgroups on.  GPUDRIVE_RANK_MIN_ROADS
+            // pins the threshold.
             int groups = 0;
             for (int w = 0; w < W; w++) groups += (w_agents[w] + 31) / 32;
             const char *pin = std::getenv("GPUDRIVE_RANK_MIN_ROADS");
-            d.rk_min_roads = pin ? std::atoi(pin) : (groups > 3 * 4 * cu_count ? GD_MAP_OBS_K : 1536);
+            d.rk_min_roads = pin ? std::atoi(pin) : (groups >= 4 * cu_count ? GD_MAP_OBS_K : 1536);
             // and not the largest worlds: with 200 ln(R / 200) inserts per agent and the superset on top, unreduced Waymo
             // scenes (5-10 thousand roads) overflow the 1280-candidate buffer for one agent in eight, which sends every group
             // of 32 to the fallback (measured: 3.80 ms ranked + fallback against 3.39 on keys alone).  Groups that keep

@@ -667,7 +667,13 @@ __global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 
 // The heap of lane `l`: slots 1..K (1-based; the reference's array index is slot - 1) as u16 ranks, two per dword:
 // pair j = (slot 2j, slot 2j + 1) at s_pair[j * 64 + l], so the children of slot g are pair g.  Slot K + 1 and, during
 // the replay, slot K (whose element lives in a register) hold 0, which is below every rank.
-constexpr int AWR = 32;  // agents per wave of the replay: two waves per SIMD at 1024 x 64 cover each other's LDS round trips
+#ifndef GD_RANK_AWR
+#define GD_RANK_AWR 64
+#endif
+// agents per wave of the replay.  The round is one dependent chain (about 140 instructions and four LDS round trips), so a
+// wave is as fast alone on its SIMD as beside a second one; measured at 1024 x 64 (us): 64 per wave 458, 32 per wave (two
+// waves per SIMD) 492, 16 per wave 674; Waymo tiles 245 / 256 / 261 (tools/build_expt.sh awr32 -DGD_RANK_AWR=32)
+constexpr int AWR = GD_RANK_AWR;
 struct RankHeap {
     unsigned int *pr;  // this lane's column
     __device__ __forceinline__ unsigned int pair(int j) const { return pr[j * AWR]; }
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
         has_tie = (packed >> 28) & 1;
         if (d.rk_fallback[i / 32] != 0) n = 0;  // the whole group is selected by k_map_obs
     }
-    const bool on = n >= K;  // never true for the upper lanes, which share LDS columns with the lower ones
+    const bool on = n >= K;  // (with fewer than 64 agents per wave: never true for the upper lanes, which share LDS columns with the lower ones)
     if (__ballot(on) == 0ull) return;
     const unsigned short *E = d.rk_E + (size_t)i * CAP;
 
