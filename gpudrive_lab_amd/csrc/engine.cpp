@@ -1111,14 +1111,15 @@ int gd_attach_bev(gd_sim *s, float *bev) {
 
 int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
 #if defined(GD_DIAG) || defined(GD_CLOCKS)
-    constexpr int32_t kLastStat = 17;
+    constexpr int32_t kLastStat = 20;
 #else
     constexpr int32_t kLastStat = 7;
 #endif
     if (!s || !out || which < 0 || which > kLastStat) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
 #if defined(GD_DIAG) || defined(GD_CLOCKS)
     if (which >= 8) {  // 8 = most crowded ranking bucket (-DGD_DIAG, GPUDRIVE_RANK_DBG=9), 10..17 = clock ticks / 256 per phase of
-                       // k_knn_rank summed over its waves (-DGD_CLOCKS); since the last read
+                       // k_knn_rank summed over its waves, 18..20 = k_knn_replay's rounds of its first wave / candidates beyond K /
+                       // inserts (-DGD_CLOCKS); since the last read
         *out = 0;
         if (s->rk_alloc) {
             int32_t v = 0;

@@ -629,7 +629,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
 }
 
 // A wave ranks several agents in turn: tens of thousands of one-agent workgroups cost more in workgroup launches (each is
-// handed its 20 KB of LDS first) than in work.
+// handed its LDS first) than in work.
 template <int A_T>
 __global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 registers: four waves per SIMD, like the LDS
     if (d.gate_any && *d.any_reset == 0) return;
@@ -801,6 +801,9 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
     // the pop's path and the push's chain are medians of three (the moved children are non-increasing down the path, the
     // chain towards the leaf): about a third fewer instructions per insert.  The other copy compares ranks without their
     // tie field and selects.
+#ifdef GD_CLOCKS
+    int n_ins = 0;  // inserts of this lane's agent (gd_stat 20: total over the agents; 19: their candidates beyond K; 18: rounds of the first wave)
+#endif
     auto replay = [&](auto ties_tag) {
         constexpr bool TIES = decltype(ties_tag)::value;
         auto lt = [](unsigned int a, unsigned int b) -> bool { return TIES ? rank_lt(a, b) : a < b; };
@@ -829,6 +832,9 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
             w8.z = (w8.z >> 16) | (w8.w << 16);
             w8.w = w8.w >> 16;
             if (p < n && lt(y, r[1])) {
+#ifdef GD_CLOCKS
+                n_ins++;
+#endif
                 // pop_heap: the hole goes from the root to the bottom of the (K - 1)-element heap along the larger child.
                 // Levels 0 and 1 are decided in registers (slots 1..7 live there during the replay); below that two levels
                 // per LDS round trip: a node's children pair and both grandchildren pairs are fetched together (pairs beyond
@@ -921,6 +927,16 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
     };
     if (__ballot(on && has_tie) != 0ull) replay(std::true_type{});
     else replay(std::false_type{});
+#ifdef GD_CLOCKS
+    {
+        const int tot_ins = wave_sum(n_ins), tot_cand = wave_sum(on ? n - K : 0), longest = wave_max(on ? n - K : 0);
+        if (lane == 0) {
+            atomicAdd(&d.rk_hist[526], tot_ins);
+            atomicAdd(&d.rk_hist[525], tot_cand);
+            if (blockIdx.x == 0) atomicAdd(&d.rk_hist[524], longest);  // rounds of the longest wave
+        }
+    }
+#endif
     // ---- the heap array, slot order, for k_knn_finish ----
     if (lane < AWR) {
         H.set(K, last);
@@ -1053,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
 
 void launch_map_obs_rank(const DevSim &d, hipStream_t st) {
     if (d.live_count == 0) return;
-    const dim3 gr(std::min((d.live_count + 7) / 8 * 8, 256 * 8 * 4)), g4((d.live_count + 3) / 4), gw(d.W * (d.A / 64));  // rank: 8 waves per CU fit (LDS), four rounds of them
+    const dim3 gr(std::min((d.live_count + 7) / 8 * 8, 256 * 8 * 4)), g4((d.live_count + 3) / 4), gw(d.W * (d.A / 64));  // rank: 8192 persistent waves, 16 per CU resident (LDS)
     if (d.A == 64) {
         hipLaunchKernelGGL((k_knn_scan<64>), gw, dim3(256), 0, st, d);
         hipLaunchKernelGGL((k_knn_rank<64>), gr, dim3(64), 0, st, d);

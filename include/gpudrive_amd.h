@@ -216,8 +216,9 @@ int gd_attach_bev(gd_sim *sim, float *bev);
  * changes a result): 3 = set-order road kernel stores its rows itself (0 / 1), 4 = its agents per wave, 5 = live agents,
  * 6 = agents per wave of the reference-order road kernel (compile-time GD_MAP_OBS_AW of this build), 7 = the
  * reference-order road selection takes the rank replay (0 / 1).  Developer builds (tools/build_expt.sh) add 8 = the most
- * crowded ranking bucket (-DGD_DIAG with GPUDRIVE_RANK_DBG=9) and 10..17 = clock ticks per phase of k_knn_rank
- * (-DGD_CLOCKS), both since the last read; otherwise GD_ERR_INVALID. */
+ * crowded ranking bucket (-DGD_DIAG with GPUDRIVE_RANK_DBG=9) and 10..17 = clock ticks per phase of k_knn_rank, then
+ * 18..20 = k_knn_replay's rounds of its first wave / candidates beyond K / inserts (-DGD_CLOCKS; tools/rank_spikes.py),
+ * all since the last read; otherwise GD_ERR_INVALID. */
 int gd_stat(gd_sim *sim, int32_t which, int64_t *out);
 
 /* Timing hooks for the bench: HIP events around the named kernel on the engine's stream (a fixed ring of event pairs,

@@ -23,6 +23,9 @@ with torch.cuda.stream(torch.cuda.Stream(device=dev)):
         ms, n = sim.kernel_timing_read(1)
         sim.kernel_timing(True)
         path = sim.debug_road_path()
+        if os.environ.get('EXPT') == 'clk':
+            longest, cand, ins = sim.stat(18), sim.stat(19), sim.stat(20)
+            print("        replay: %d candidates beyond K, %d inserts (%.1f %% fail), longest wave %d rounds" % (cand, ins, 100 - 100 * ins / max(cand, 1), longest))
         ph = np.array([sim.stat(10 + q) for q in range(7)], np.float64) if os.environ.get('EXPT') == 'clk' else np.zeros(7)
         print("step %2d road obs %.0f us  widest bucket %d  ranked %d fallback %d far %d max n %d  k_knn_rank phases %% (between agents, words, keys, "
               "count+prefix, scatter, order in buckets, write-out): %s" %
