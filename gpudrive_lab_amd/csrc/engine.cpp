@@ -144,9 +144,10 @@ struct gd_sim {
         d.cp_hdr = alloc_internal<float4>(2 * WA);
         d.rk_words = alloc_internal<uint32_t>(WA * GD_RANK_NCH);
         d.rk_tl = alloc_internal<float>(WA);
-        d.rk_hist = alloc_internal<int32_t>(528);
+        d.rk_hist = alloc_internal<int32_t>(544);
         d.rk_ticket = alloc_internal<int32_t>(WA);
         d.rk_order = alloc_internal<int32_t>(WA);
+        d.rk_list = alloc_internal<int32_t>(8 * WA);
         d.road_bbox = alloc_internal<float4>(W);
         rk_alloc = true;
     }
@@ -627,10 +628,6 @@ struct gd_sim {
                     if (a < w_agents[w]) live.push_back(w * A + a);
             d.live_count = static_cast<int>(live.size());
             if (!live.empty()) HIP_CHECK(hipMemcpy(d.live_list, live.data(), sizeof(int32_t) * live.size(), hipMemcpyHostToDevice));
-            live.clear();
-            for (int w = 0; w < W; w++)  // world-major: the rank kernel wants neighbours in the list to share their roads
-                for (int a = 0; a < w_agents[w]; a++) live.push_back(w * A + a);
-            if (!live.empty()) HIP_CHECK(hipMemcpy(d.live_wm, live.data(), sizeof(int32_t) * live.size(), hipMemcpyHostToDevice));
             // likewise the set-order road kernel's workgroups (4 waves x set_apw agents each)
             std::vector<int32_t> groups;
             const int per = 4 * d.set_apw;
@@ -740,6 +737,7 @@ struct gd_sim {
         HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemset(d.rk_fallback, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
         HIP_CHECK(hipMemset(d.rk_streak, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
+        HIP_CHECK(hipMemset(d.rk_hist, 0, sizeof(int32_t) * 544));  // bin counts, the lists of ranked agents: empty
     }
 
     void do_reset(const std::vector<int32_t> &flags) {
@@ -926,7 +924,6 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.gate_any = 0;
         d.road_off = s->alloc_internal<int32_t>(W + 1);
         d.live_list = s->alloc_internal<int32_t>(WA);
-        d.live_wm = s->alloc_internal<int32_t>(WA);
         d.live_count = 0;
         d.set_groups = s->alloc_internal<int32_t>(WA);
         d.set_group_count = 0;

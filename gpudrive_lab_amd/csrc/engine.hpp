@@ -50,7 +50,6 @@ struct DevSim {
     int knn_order;    // GD_KNN_*
     int set_fused_rows;  // set-order mode: the selection kernel writes the rows itself (several generations of workgroups, ragged batches)
     int32_t *live_list;  // [W * A] world * A + agent of every live agent, agent-major (rebuilt with the worlds)
-    int32_t *live_wm;    // [W * A] the same agents world by world (k_knn_rank: neighbours in the list share their road points)
     int live_count;
     int32_t *set_groups;  // set-order kernel: (world << 8 | group) of every group of 4 * set_apw agent slots that holds a live agent
     int set_group_count;
@@ -109,9 +108,10 @@ struct DevSim {
     uint16_t *rk_spc;      // [W][A][CAP] sorted slot -> road index
     uint32_t *rk_heap;     // [W][A][GD_RANK_HEAP_DW] the replayed heap array as rank pairs
     uint16_t *rk_cpe;      // [W][A][NCP] rank on top of the heap at every checkpoint of this selection
-    int32_t *rk_hist;      // [528] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path, selections so far; [514..523] counters of -DGD_DIAG builds
+    int32_t *rk_hist;      // [544] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path, selections so far; [514..526] counters of developer builds; [528..535] entries of rk_list
     int32_t *rk_ticket;    // [W][A] bin << 20 | place inside the bin (bit 30: fell back after taking it); -1 = not on the rank path this step; < -1: why
     int32_t *rk_order;     // [W][A] agents on the rank path, most candidates first
+    int32_t *rk_list;      // [8][W][A] agents on the rank path, one list per XCD that scanned them (counts: rk_hist[528..535])
     uint32_t *rk_words;    // [W][A][NCH] candidate bits of 32 roads, one row per agent (k_knn_scan -> k_knn_rank)
     float *rk_tl;          // [W][A] the last K-th key of the checkpoint set in use (scales the ranking buckets)
     const float4 *road_bbox;  // [W] (min x, min y, max x, max y) over the world's roads

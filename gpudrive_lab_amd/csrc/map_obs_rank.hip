@@ -119,6 +119,8 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
 
     float ex = 0.f, ey = 0.f;
     if (live) { ex = d.px[i]; ey = d.py[i]; }
+    unsigned long long ranked = 0ull;  // wave 0: its lanes whose agents take the rank path ...
+    int list_base = 0;                 // ... and where they go in rk_list
     if (wave == 0) {
         int ncp = 0;
         if (live) {
@@ -174,6 +176,12 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
             if (state == RK_FAR) ncp = 0;
         }
         s_ncp[lane] = ncp;
+        // the agents on the rank path, as a list: k_knn_rank's waves share THEM out, not the live agents (on the Waymo tiles
+        // five agents in six are parked out of reach of every road, and a wave that drew three of the others set the pace).
+        // One list per XCD (workgroup b runs on XCD b % 8; k_knn_rank's waves take the list of their own XCD, so an agent's
+        // road points are gathered into the L2 that scanned them, and eight counters are asked instead of one: a thousand
+        // workgroups adding to one address at once cost the kernel 10 us)
+        ranked = __ballot(ncp > 0);
     }
     __syncthreads();
     const int ncp = s_ncp[lane];
@@ -189,6 +197,10 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
         __syncthreads();
         for (int r = tile + tid; r < min(R, tile + SCAN_TILE); r += 256) s_xy[r - tile] = d.road_xy[r0 + r];
         __syncthreads();
+        // the place of this workgroup's ranked agents in their list: asked for once the wave's last loads are in (memory
+        // operations complete in order: asked earlier it held up the road loads, asked at the very end nothing hides it)
+        if (wave == 0 && ranked != 0ull && lane == 0 && tile + SCAN_TILE >= R)
+            list_base = atomicAdd(&d.rk_hist[528 + (blockIdx.x & 7)], __popcll(ranked));
 #pragma clang loop unroll(disable)
         for (int c_first = (tile >> 5) + wave * 16; c_first < (tile >> 5) + wave * 16 + 16 && c_first < nch; c_first += TB) {
 #pragma clang loop unroll(disable)
@@ -221,6 +233,10 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
             }
             wave_sync();
         }
+    }
+    if (wave == 0 && ranked != 0ull) {
+        list_base = __builtin_amdgcn_readfirstlane(list_base);
+        if (ncp > 0) d.rk_list[(size_t)(blockIdx.x & 7) * WA + list_base + __popcll(ranked & ((1ull << lane) - 1ull))] = (int)i;
     }
 }
 
@@ -259,10 +275,10 @@ __device__ __forceinline__ T uniform_load(const T *p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
 }
 template <int A_T>
-__device__ __forceinline__ RankIn rank_fetch(const DevSim &d, int li, int lane) {
+__device__ __forceinline__ RankIn rank_fetch(const DevSim &d, const int *list, int li, int count, int lane) {
     RankIn in;
-    in.i = li < d.live_count ? uniform_load(d.live_wm + li) : 0;
-    in.state = li < d.live_count ? uniform_load(d.rk_n + in.i) : 0;  // (k_knn_scan's; this kernel rewrites it once the agent is ranked)
+    in.i = li < count ? uniform_load(list + li) : 0;
+    in.state = li < count ? uniform_load(d.rk_n + in.i) : 0;  // (k_knn_scan's; this kernel rewrites it once the agent is ranked)
     const int w = in.i / A_T;
     in.r0 = uniform_load(d.road_off + w);
     in.R = uniform_load(d.road_off + w + 1) - in.r0;
@@ -297,11 +313,11 @@ struct PhaseClock {};
 #endif
 template <int A_T>
 __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds &L, PhaseClock &clk, int next_entry,
-                                           RankIn &nxt) {
+                                           int count, const int *list, RankIn &nxt) {
     // The next agent's inputs are requested in the middle of this one, behind the last gather of the keys: vector memory
     // operations complete in order, so requested up front they (1.3 KB from HBM) were what every gather then waited for.
     if (__builtin_amdgcn_readfirstlane(in.state) != 1) {  // fallback or too far from every road (k_knn_scan)
-        nxt = rank_fetch<A_T>(d, next_entry, lane);
+        nxt = rank_fetch<A_T>(d, list, next_entry, count, lane);
         return;
     }
     // every lane fetched the same values: as scalars they index through scalar base addresses (a per-lane 64-bit pointer per
@@ -346,7 +362,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             d.rk_ticket[i] = -3;  // more candidates than the buffer holds
             d.rk_fallback[group] = 1;
         }
-        nxt = rank_fetch<A_T>(d, next_entry, lane);
+        nxt = rank_fetch<A_T>(d, list, next_entry, count, lane);
         return;
     }
     wave_sync();
@@ -357,7 +373,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     if (lane == 0) ticket = bin << 20 | atomicAdd(&d.rk_hist[bin], 1);
     GD_PHASE(1);
     if (GD_DIAG_IS(d.rk_dbg, 1)) {
-        nxt = rank_fetch<A_T>(d, next_entry, lane);
+        nxt = rank_fetch<A_T>(d, list, next_entry, count, lane);
         return;
     }
     // where this selection's checkpoints start to apply (their K-th distances are filled in by k_knn_finish): checkpoint 0
@@ -418,7 +434,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             }
         }
     }
-    nxt = rank_fetch<A_T>(d, next_entry, lane);
+    nxt = rank_fetch<A_T>(d, list, next_entry, count, lane);
     nle = wave_sum(nle);
     kmax_seen = wave_max_nonneg(kmax_seen);  // keys are sums of squares
     kmin_seen = wave_min_nonneg(kmin_seen);
@@ -634,24 +650,25 @@ template <int A_T>
 __global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 registers: four waves per SIMD, like the LDS
     if (d.gate_any && *d.any_reset == 0) return;
     __shared__ RankLds L;
-    // Which agents a wave takes.  The live agents are listed world by world (live_wm); workgroup b runs on XCD b % 8, and a
-    // world's 64-entry chunk of the list goes to the waves of ONE XCD, so that the road points its agents gather (32 KB per
-    // world on the bench scene) are fetched into one L2 instead of eight, and the waves resident at a time work on a few dozen
-    // worlds instead of all of them (in agent-major order every generation of waves touched every world: 32 MB against 4 MB of
-    // L2 per XCD).  The t-th entry of XCD x's sequence is entry t % 64 of chunk (t / 64) * 8 + x.
+    // Which agents a wave takes: workgroup b runs on XCD b % 8 and shares out the list of the agents that k_knn_scan's
+    // workgroups on that XCD put on the rank path (rk_list), one entry per wave and turn.  The road points an agent gathers
+    // (32 KB per world on the bench scene) are then in that XCD's L2 already, and the waves resident at a time work on a few
+    // dozen worlds instead of all of them (in agent-major order every generation of waves touched every world: 32 MB against
+    // 4 MB of L2 per XCD; HBM bytes of the road observation 2.16 -> 1.36 GB per step).
     const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7;  // (the grid is a multiple of 8 workgroups)
-    auto entry = [&](int t) -> int { return (((t >> 6) * 8 + xcd) << 6) + (t & 63); };
+    const int count = uniform_load(d.rk_hist + 528 + xcd);
+    const int *list = d.rk_list + (size_t)xcd * d.W * A_T;
     int t = blockIdx.x >> 3;
-    RankIn cur = rank_fetch<A_T>(d, entry(t), threadIdx.x);
+    RankIn cur = rank_fetch<A_T>(d, list, t, count, threadIdx.x);
     PhaseClock clk;
 #ifdef GD_CLOCKS
     for (int k = 0; k < 8; k++) clk.sum[k] = 0u;
     clk.prev = (unsigned int)__builtin_amdgcn_s_memtime();
 #endif
-    for (; entry(t) < d.live_count; t += per_xcd) {  // (entries grow with t: the first one beyond the list ends the wave)
+    for (; t < count; t += per_xcd) {
         RankIn nxt;
         GD_PHASE(0);  // between agents: the buffers change hands
-        rank_agent<A_T>(d, cur, threadIdx.x, L, clk, entry(t + per_xcd), nxt);
+        rank_agent<A_T>(d, cur, threadIdx.x, L, clk, t + per_xcd, count, list, nxt);
         wave_sync();  // the LDS buffers change hands
         cur = nxt;
     }
@@ -703,6 +720,7 @@ __global__ __launch_bounds__(256) void k_knn_bins(DevSim d) {
     if (t == 255) {
         d.rk_hist[512] = before + incl;  // agents on the rank path
         d.rk_hist[513]++;                // selections so far (k_knn_scan staggers the retries of bypassing groups with it)
+        for (int x = 0; x < 8; x++) d.rk_hist[528 + x] = 0;  // the next selection's lists of ranked agents start empty
     }
 }
 
