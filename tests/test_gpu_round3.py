@@ -1,7 +1,8 @@
 """GPU suite, round 3: the rank replay of the reference-order road selection (csrc/map_obs_rank.hip) against the history
 replay on keys it falls back to and against the oracle; oracle cross-checks at BASELINE.json's full sizes (first and last
 worlds of the batch, both workgroup generations, config 5); the road arrays' slack when a rebuild fits the old capacity;
-the set-order kernel's rule for ties at the K-th key.  Everything goes through `madrona_gpudrive` -> ctypes -> the C ABI."""
+the set-order kernel's rule for ties at the K-th key; the reference's OBB known-answer cases as worlds of two parked vehicles.
+Everything goes through `madrona_gpudrive` -> ctypes -> the C ABI."""
 import collections
 import json
 
@@ -384,4 +385,51 @@ def test_set_order_ties_at_the_kth_key(oracle_mod, tmp_path):
     assert straddles > 0, "no agent had duplicated roads at its K-th distance: the scene does not exercise the tie rule"
     print("ties at the K-th key: %d agent-steps; the reference kept the lowest road index in %d of them, the twin in %d"
           % (straddles, same_choice, other_choice))
+    gpu.close()
+
+
+# ---- the reference's OBB known-answer cases (tests/CollisionDetectionTests.cpp:11-85) on the device ----
+def _two_boxes(tmp_path, name, pos_b, yaw_b, half_a, half_b):
+    """Two parked vehicles whose boxes have the given half extents (the engine scales length / 2 and width / 2 by 0.7,
+    src/level_gen.cpp), the first at the origin with yaw 0; one far road so that the world has a map."""
+    def obj(i, x, y, yaw, half):
+        return {"position": [{"x": 100.0 + x, "y": 50.0 + y, "z": 0.0}] * 91, "width": 2.0 * half[1] / 0.7,
+                "length": 2.0 * half[0] / 0.7, "height": 1.6, "heading": [yaw] * 91, "velocity": [{"x": 0.0, "y": 0.0}] * 91,
+                "valid": [True] * 91, "goalPosition": {"x": 400.0, "y": 400.0, "z": 0.0}, "type": "vehicle", "id": i,
+                "mark_as_expert": False}
+    sc = {"name": name, "scenario_id": name, "objects": [obj(0, 0.0, 0.0, 0.0, half_a), obj(1, pos_b[0], pos_b[1], yaw_b, half_b)],
+          "roads": [{"geometry": [{"x": 300.0 + k, "y": 300.0, "z": 0.0} for k in range(8)], "type": "road_edge",
+                     "map_element_id": 15, "id": 0}],
+          "tl_states": {}, "metadata": {"sdc_track_index": 0, "objects_of_interest": [], "tracks_to_predict": []}}
+    p = tmp_path / (name + ".json")
+    p.write_text(json.dumps(sc))
+    return str(p)
+
+
+def test_obb_known_answer_cases_on_the_hip_path(oracle_mod, tmp_path):
+    """Each case is a world of two parked vehicles; one step with zero actions; the collision flags of `info_tensor` must be
+    what the reference's test expects and what the oracle computes from the same scene.  (The touching-corners case is
+    compared with the oracle only: the half extents go through length / 2 * 0.7 in float.)"""
+    import math
+    cases = [("aligned", (1.0, 1.0), 0.0, (1.0, 1.0), (1.0, 1.0), True),
+             ("apart", (2.0, 2.0), 0.0, (0.5, 0.5), (0.5, 0.5), False),
+             ("corner", (1.0, 1.0), 0.0, (0.5, 0.5), (0.5, 0.5), None),
+             ("inside", (0.0, 0.0), 0.0, (1.0, 1.0), (0.5, 0.5), True)]
+    cases += [("rot%03d" % deg, (0.5, 0.5), math.radians(deg), (1.0, 1.0), (1.0, 1.0), True) for deg in range(0, 360, 15)]
+    scenes = [_two_boxes(tmp_path, n, pb, yb, ha, hb) for n, pb, yb, ha, hb, _ in cases]
+    kw = dict(CLASSIC, collisionBehaviour=2)
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    zero = np.zeros((len(scenes), 64, 10), np.float32)
+    RC.write_actions(gpu, zero)
+    RC.write_actions(orc, zero)
+    gpu.step()
+    orc.step()
+    P.compare_ints(gpu, orc)
+    info = RC.as_np(gpu.info_tensor())
+    for w, (name, _, _, _, _, expect) in enumerate(cases):
+        hit = info[w, :2, 1] != 0   # column 1: collided with a vehicle (src/types.hpp Info)
+        assert hit[0] == hit[1], name
+        if expect is not None:
+            assert bool(hit[0]) == expect, "%s: the device says %s" % (name, bool(hit[0]))
     gpu.close()
