@@ -494,7 +494,11 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     if (blockIdx.x == 0 && d.knn_order != GD_KNN_SET_ORDER)
         order_waves<256>(d, d.W * (A_T / AW), reinterpret_cast<unsigned int *>(s_rows));
     const size_t rows = (size_t)d.W * A_T * K;
-    const size_t base = (size_t)blockIdx.x * RB;
+    // Which rows a workgroup takes: workgroup b runs on XCD b % 8, and the XCDs take eighths of the tensor, so that a world's
+    // road records (128 KB on the bench scene, gathered in heap order) are fetched into one L2 instead of all eight
+    const unsigned int per_xcd = gridDim.x >> 3;  // (the grid is a multiple of 8 workgroups)
+    const size_t base = (size_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * RB;
+    if (base >= rows) return;
     // the agent's header (pose, count, first road: written by the selection kernel) and the slot's road index come in one
     // round trip, the road's 32-byte record in a second one
     bool on[U], in[U];
@@ -1270,7 +1274,7 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);
     }
     const size_t rows = (size_t)d.W * d.A * K;
-    const dim3 rgrid((unsigned int)((rows + 256 * GD_ROWS_PER_THREAD - 1) / (256 * GD_ROWS_PER_THREAD)));
+    const dim3 rgrid((unsigned int)((rows + 256 * GD_ROWS_PER_THREAD - 1) / (256 * GD_ROWS_PER_THREAD) + 7) / 8 * 8);
     if (d.A == 64) hipLaunchKernelGGL((k_map_rows<64>), rgrid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((k_map_rows<128>), rgrid, dim3(256), 0, st, d);
 }
