@@ -19,6 +19,8 @@ Two stretches of K steps per workload, back to back on the same simulator:
   2. the same K steps again with HIP events on the engine's stream around every launch (`gd_kernel_timing_*`: the
      kernels are then launched one by one): `kernels`, `roofline.avg_kernel_us`, and that stretch's own wall clock
      `ms_per_step_events`, which the kernel averages add up to.
+Each stretch starts at the first step of an episode (after untimed spin-up steps, `spin_up_steps` in the line), so that it
+holds K // 91 episode resets in every run (`timed_region.episode_resets`).
 With N > 1 ranks a further stretch measures BASELINE configs[3]'s observation all-gather (RCCL), overlapped
 with the following step (`allgather` in the line; `--gather none` skips it).  `--headless` adds the two FPS lines of the
 reference's own benchmark CLI (src/headless.cpp:145-155) on stderr.
@@ -187,14 +189,21 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         # builds the worlds for a second or more) this GPU delays the first work it is given by 10-90 ms in about one
         # stretch out of twelve -- the kernels then run at full speed, the wall clock of a 20-step stretch triples; with
         # the device kept busy for 200 ms first it did not happen in 60 stretches (tools/stall_probe2.py).
+        if not KEEP_GC:  # (collected before the spin-up, not after it: the device must not idle between the spin-up and t0)
+            gc.collect()
+            gc.disable()
         t_spin = time.perf_counter()
         while 1e3 * (time.perf_counter() - t_spin) < args.spin_ms:
             k = run_steps(sim, batches, all_worlds, 4, start=k, tracker=tracker)
             spin_steps[0] += 4
             torch.cuda.synchronize(device)
-        if not KEEP_GC:
-            gc.collect()
-            gc.disable()
+        # ... and on to the start of an episode, so that the stretch holds the same number of episode resets (every 91st step:
+        # a second observation pass, 1.4 ms on the bench scene) in every run: K // 91 of them.  With a time-based spin-up
+        # alone the driver's 20-step stretch caught one in some runs (1.30 ms per step) and none in others (1.25)
+        while k % EPISODE != 0:
+            k = run_steps(sim, batches, all_worlds, 1, start=k, tracker=tracker)
+            spin_steps[0] += 1
+        torch.cuda.synchronize(device)
         sharding.barrier(device)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
@@ -229,7 +238,7 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         live_agents_per_rank=live, road_entities_per_rank=roads, init_seconds=init_s,
         agent_steps_per_s=total_live * args.steps / elapsed,
         padded_agent_steps_per_s=world * args.worlds * args.agents * args.steps / elapsed,
-        timed_region=dict(graph_steps=graph_steps, plain_steps=plain_steps),
+        timed_region=dict(graph_steps=graph_steps, plain_steps=plain_steps, episode_resets=args.steps // EPISODE),
         gc_ms_in_timed_stretches=gc_ms[0], spin_up_steps=spin_steps[0],
         worlds=args.worlds,
     )
