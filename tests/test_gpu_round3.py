@@ -41,17 +41,19 @@ def _bits(t):
     return RC.as_np(t).view(np.uint32)
 
 
-@pytest.mark.parametrize("which", ["bench", "waymo", "waymo_agent_stop", "waymo_unreduced", "equal_keys"])
+@pytest.mark.parametrize("which", ["bench", "waymo", "waymo_128_slots", "waymo_agent_stop", "waymo_unreduced", "equal_keys"])
 def test_rank_replay_equals_history_replay_bit_for_bit(bench_scenes, tmp_path, monkeypatch, which):
     """Two engines on the same scenes and actions, free running: one selects the roads with the rank replay, the other
     with GPUDRIVE_NO_RANK_REPLAY=1 (k_map_obs alone, round 2's kernel).  agent_roadmap_tensor must be bit-identical at
     every step -- through a reset of some worlds, a jump of a few agents (their bounds no longer hold) and agents that
     finish and are parked at the padding position -- and the rank replay must actually have been taken."""
-    min_taken = 0.6
+    min_taken, slots = 0.6, 64
     if which == "bench":
         scenes, kw = bench_scenes[:3], BENCH
     elif which == "waymo":
         scenes, kw = [TEST_JSON, SCENE_407, SCENE_4], CLASSIC   # a few hundred roads per world: every road may be a candidate
+    elif which == "waymo_128_slots":
+        scenes, kw, slots = [TEST_JSON, SCENE_407, SCENE_4], CLASSIC, 128   # the kernels' 128-slot instantiations (two halves per world)
     elif which == "waymo_agent_stop":
         # BASELINE configs[2]'s rules.  Agents come back from the padding position with checkpoints that were recorded out
         # there (every road a candidate, all of them far below the recorded K-th key): the ranking's buckets then go by
@@ -67,9 +69,9 @@ def test_rank_replay_equals_history_replay_bit_for_bit(bench_scenes, tmp_path, m
         scenes, kw, min_taken = [_dup_scene(tmp_path), SCENE_407], dict(BENCH, observationRadius=200.0), 0.4
     monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")   # small worlds too (by default k_map_obs keeps those)
     monkeypatch.setenv("GPUDRIVE_RANK_MAX_ROADS", "20000")  # and the largest (by default left to k_map_obs as well)
-    fast = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    fast = P.make_gpu_sim(scenes, max_agents=slots, **kw)
     monkeypatch.setenv("GPUDRIVE_NO_RANK_REPLAY", "1")
-    slow = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    slow = P.make_gpu_sim(scenes, max_agents=slots, **kw)
     monkeypatch.delenv("GPUDRIVE_NO_RANK_REPLAY")
     assert fast.stat(7) == 1 and slow.stat(7) == 0
     assert (slow.debug_road_path() == -2).all()
@@ -89,7 +91,7 @@ def test_rank_replay_equals_history_replay_bit_for_bit(bench_scenes, tmp_path, m
             assert np.array_equal(_bits(getattr(fast, name)()), _bits(getattr(slow, name)())), (tag, name)
     same("t=0")
     for k in range(24):
-        act = P.random_actions(rng, W, 64, 0)
+        act = P.random_actions(rng, W, slots, 0)
         RC.write_actions(fast, act)
         RC.write_actions(slow, act)
         fast.step()
