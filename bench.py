@@ -87,8 +87,15 @@ WAYMO = [os.path.join(ROOT, "tests", "data", n) for n in
 
 
 def split_workload(name):
-    """'synthetic_set' -> ('synthetic', 1): the same scenes with gd_config.knn_order = GD_KNN_SET_ORDER."""
-    return (name[:-4], 1) if name.endswith("_set") else (name, 0)
+    """'synthetic_set' -> ('synthetic', 1, None): the same scenes with gd_config.knn_order = GD_KNN_SET_ORDER;
+    'synthetic_128' -> ('synthetic', 0, 128): the same generator with the fork's own kMaxAgentCount = 128 agent slots
+    (reference src/consts.hpp:11), every one of them live."""
+    order, agents = 0, None
+    if name.endswith("_set"):
+        name, order = name[:-4], 1
+    if name.endswith("_128"):
+        name, agents = name[:-4], 128
+    return name, order, agents
 
 
 def params_for(workload):
@@ -104,10 +111,10 @@ def params_for(workload):
     return kw
 
 
-def scenes_for(workload, worlds, rank):
+def scenes_for(workload, worlds, rank, agents=64):
     if workload in ("synthetic", "rl_loop"):
-        d = os.path.join(tempfile.gettempdir(), "gpudrive_amd_bench_scenes")
-        paths = synth.write_scenes(d, [rank * 1000 + i for i in range(8)])
+        d = os.path.join(tempfile.gettempdir(), "gpudrive_amd_bench_scenes" + ("" if agents == 64 else "_%d" % agents))
+        paths = synth.write_scenes(d, [rank * 1000 + i for i in range(8)], n_agents=agents)
         return [paths[i % len(paths)] for i in range(worlds)]
     return sharding.scene_list_for_rank(WAYMO, worlds, rank)
 
@@ -159,12 +166,14 @@ def bench_workload(workload, args, rank, local_rank, world, device):
 
 
 def _bench_workload(name, args, rank, local_rank, world, device):
-    workload, knn_order = split_workload(name)
+    workload, knn_order, agents_override = split_workload(name)
     knn_order = max(knn_order, args.knn_order)
     kw = params_for(workload)
     if workload == "cfg3":
         args = argparse.Namespace(**dict(vars(args), worlds=4 * args.worlds))
-    scenes = scenes_for(workload, args.worlds, rank)
+    if agents_override:
+        args = argparse.Namespace(**dict(vars(args), agents=agents_override))
+    scenes = scenes_for(workload, args.worlds, rank, args.agents)
     t0 = time.time()
     sim = make_sim(scenes, kw, args.agents, local_rank, knn_order=knn_order,
                    lidar_half_angle=float(np.pi) if workload == "lidar" else 0.0,  # 360 degrees
@@ -184,7 +193,7 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     gc_ms = [0.0]
     spin_steps = [0]
 
-    def timed_stretch(k):
+    def timed_stretch(k, pre_t0=None):
         # Device spin-up: untimed steps for --spin-ms of wall clock right before the stretch.  After an idle period (the host
         # builds the worlds for a second or more) this GPU delays the first work it is given by 10-90 ms in about one
         # stretch out of twelve -- the kernels then run at full speed, the wall clock of a 20-step stretch triples; with
@@ -200,10 +209,16 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         # ... and on to the start of an episode, so that the stretch holds the same number of episode resets (every 91st step:
         # a second observation pass, 1.4 ms on the bench scene) in every run: K // 91 of them.  With a time-based spin-up
         # alone the driver's 20-step stretch caught one in some runs (1.30 ms per step) and none in others (1.25)
-        while k % EPISODE != 0:
-            k = run_steps(sim, batches, all_worlds, 1, start=k, tracker=tracker)
-            spin_steps[0] += 1
+        # (--no-align: profiler passes, whose counters would otherwise average over up to 90 alignment steps per stretch.
+        # With N ranks every rank steps on to the furthest rank's k, so that all of them reach the barrier together.)
+        if not args.no_align:
+            target = int(sharding.reduce_max(float(-(-k // EPISODE) * EPISODE), device)) if world > 1 else -(-k // EPISODE) * EPISODE
+            while k < target:
+                k = run_steps(sim, batches, all_worlds, 1, start=k, tracker=tracker)
+                spin_steps[0] += 1
         torch.cuda.synchronize(device)
+        if pre_t0 is not None:
+            pre_t0()  # counters that must cover the K timed steps and nothing else start here
         sharding.barrier(device)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
@@ -217,17 +232,18 @@ def _bench_workload(name, args, rank, local_rank, world, device):
 
     k = run_steps(sim, batches, all_worlds, args.warmup, tracker=tracker)
     # ---- 1. the timed region: step() as a user calls it (hipGraph replay, no instrumentation) ----
-    graph0, plain0 = sim.stat(0), sim.stat(1)
-    k, local_elapsed = timed_stretch(k)
-    graph_steps, plain_steps = sim.stat(0) - graph0, sim.stat(1) - plain0
+    base = {}
+    k, local_elapsed = timed_stretch(k, pre_t0=lambda: base.update(graph=sim.stat(0), plain=sim.stat(1)))
+    graph_steps, plain_steps = sim.stat(0) - base["graph"], sim.stat(1) - base["plain"]
     elapsed = sharding.reduce_max(local_elapsed, device)
     elapsed_min = -sharding.reduce_max(-local_elapsed, device)
     # ---- 2. the same K steps again with HIP events around every kernel launch (kernel by kernel); a few untimed steps
     # first so that nothing of the switch (event creation, first plain launches) lands in the stretch ----
     sim.kernel_timing(True)
     k = run_steps(sim, batches, all_worlds, 3, start=k, tracker=tracker)
-    sim.kernel_timing(True)  # zeroes the sums
-    k, ev_elapsed = timed_stretch(k)
+    # the sums are zeroed after the spin-up and the alignment steps, right before the barrier and t0: `launches` == K
+    # (+ the stretch's episode resets) and `kernels_sum_us` is comparable with `ms_per_step_events`
+    k, ev_elapsed = timed_stretch(k, pre_t0=lambda: sim.kernel_timing(True))
     ev_elapsed = sharding.reduce_max(ev_elapsed, device)
     total_live = sharding.reduce_sum(live, device)
     res = dict(
@@ -259,6 +275,11 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     # algorithmic bytes per launch, SURVEY.md 8d: per world 36*R_w + 16*N_w + 7200*N_w (road selection + row write-out:
     # k_map_obs hands its selection to k_map_rows; the two launches are one reference system and are timed together)
     alg_bytes = 36.0 * roads + (16.0 + 7200.0) * live
+    # ... and what THIS design cannot move less than (a strict lower bound of its HBM traffic): the scan reads an 8-byte
+    # (x, y) per road once per world, a world's agents gather at least K distinct 32-byte road records between them, and
+    # every live agent's header (16 B) + K rows (7200 B) are written.  `traffic` (PMC) can be below the SURVEY figure
+    # (its 36 B per road is not what this layout reads) but never below this one.
+    design_min = float(sum(8.0 * int(r) + 32.0 * min(int(r), 200) + 7216.0 * int(n) for n, r in shape))
     avg_s = kt["k_map_obs+k_map_rows"]["avg_us"] * 1e-6
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     res["kernels"] = kt
@@ -271,15 +292,25 @@ def _bench_workload(name, args, rank, local_rank, world, device):
             tkey = ("set_" if knn_order == 1 else "exact_") + workload
         else:  # lidar, bev, rl_loop: collected in the default (reference) row order only
             tkey = workload if knn_order == 0 else ("set_cfg3" if workload == "cfg3" else None)
-        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
-            tj = json.load(fh)
-        if tj.get("source_stamp") == source_stamp() and args.worlds == (4096 if workload == "cfg3" else 1024) and args.agents == 64:
-            traffic = tj.get(tkey, {}).get("hbm_bytes_per_launch")
+        if agents_override:
+            tkey = (tkey or "") + "_128"
+        stamp = source_stamp()
+        for tname in sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_traffic.json") and n[:1] == "r"),
+                            reverse=True):  # newest round first; only a file collected on THIS build counts
+            with open(os.path.join(ROOT, "profiles", tname)) as fh:
+                tj = json.load(fh)
+            if tj.get("source_stamp") == stamp and args.worlds == (4096 if workload == "cfg3" else 1024):
+                traffic = tj.get(tkey, {}).get("hbm_bytes_per_launch")
+                break
     except Exception:
         traffic = None
     res["roofline"] = dict(bound="hbm", kernel="k_map_obs+k_map_rows", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                            frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                           algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt["k_map_obs+k_map_rows"]["avg_us"])
+                           algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt["k_map_obs+k_map_rows"]["avg_us"],
+                           design_min_bytes_per_launch=design_min,
+                           denominators="algorithmic_bytes_per_launch = SURVEY 8d's contract (36 R_w + 7216 N_w per world-step); "
+                                        "design_min_bytes_per_launch = this layout's own floor (8 R_w scanned once per world + 32 B x "
+                                        "min(R_w, K) gathered records + 7216 N_w written): traffic >= the second, not necessarily the first")
     # the other kernels with a SURVEY 8d byte count, same steps
     extra = {}
     if "k_lidar" in kt and kt["k_lidar"]["avg_us"] > 0:
@@ -304,6 +335,10 @@ def _bench_workload(name, args, rank, local_rank, world, device):
                                            frac=part / t / 1e9 / HBM_PEAK_GBS, unit="GB/s",
                                            note="runs on a second stream beside the road observation")
     res["other_rooflines"] = extra
+    # how many of the live agents see any road at all at the end of the run (a finished agent parked at the padding
+    # position is out of reach of every road: no selection work, 7200 B of padding rows all the same)
+    amap = sim.agent_roadmap_tensor().to_torch()
+    res["live_agents_with_roads_in_reach"] = int((amap[..., 6] > 0).any(dim=-1).sum().item())
     res["kernels_sum_us"] = sum(v["avg_us"] for v in kt.values())
     res["overlapped_kernels"] = overlapped
     res["engine"] = dict(graph_steps=sim.stat(0), plain_steps=sim.stat(1), graph_captures=sim.stat(2),
@@ -429,12 +464,21 @@ def main():
                     help="N > 1 only: after the timed region, a stretch with the observation all-gather of BASELINE configs[3] "
                          "(raw = every agent slot's packed observation, compact = controlled agents only), overlapped with the next step")
     ap.add_argument("--gather-steps", type=int, default=30)
-    ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop,synthetic_set,waymo_set,cfg3_set",
-                    help="first = primary; synthetic | waymo | cfg3 | lidar (Waymo tiles + 360-degree LiDAR) | bev | rl_loop; "
-                         "a _set suffix = the same scenes in set order (knn_order 1)")
+    ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop,synthetic_128,waymo_raw,synthetic_set,waymo_set,cfg3_set",
+                    help="first = primary; synthetic | waymo | cfg3 | lidar (Waymo tiles + 360-degree LiDAR) | bev | rl_loop | "
+                         "waymo_raw (the Waymo tiles with unreduced polylines, the setting of the reference's C++ tests); "
+                         "a _128 suffix = 128 agent slots per world (the fork's kMaxAgentCount), a _set suffix = the same scenes "
+                         "in set order (knn_order 1)")
     ap.add_argument("--spin-ms", type=float, default=200.0,
                     help="untimed steps for this many ms of wall clock before each timed stretch (device spin-up after the idle "
                          "world build; 0 = none)")
+    ap.add_argument("--no-align", action="store_true",
+                    help="do not run on to the first step of an episode before a timed stretch (profiler passes: their counter "
+                         "means would otherwise cover up to 90 alignment steps per stretch)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: every rank joins the process group, the ranks are counted with one all-reduce and rank 0 "
+                         "prints a line with `distributed` filled in (checks the launch path, e.g. on a CPU-only box with "
+                         "--dist-backend gloo)")
     ap.add_argument("--headless", action="store_true",
                     help="also print the reference CLI's two lines (src/headless.cpp:145-155) for the primary workload on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -444,6 +488,36 @@ def main():
     ap.add_argument("--knn-order", type=int, default=0, choices=(0, 1),
                     help="0 = reference heap order (default, elementwise parity); 1 = same row set, road-index order")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as CHILD processes
+    # (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) and BEFORE anything here touches the GPU -- a
+    # process that has initialised HIP must never be replaced or forked.  The children print rank 0's JSON line on our
+    # stdout; our exit code is theirs.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: --gpus %d without a launcher: spawning %s\n" % (args.gpus, " ".join(cmd[1:9])))
+        raise SystemExit(subprocess.call(cmd))
+
+    if args.dry_run:
+        rank, local_rank, world = sharding.init_process_group(backend=args.dist_backend or "gloo")
+        if world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        import torch.distributed as dist
+        seen = torch.ones(1)
+        if dist.is_initialized():
+            dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_counted": int(seen.item()),
+                              "distributed": dict(world_size=dist.get_world_size(), backend=dist.get_backend())
+                              if dist.is_initialized() else None}), flush=True)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the step path has no CPU fallback")
@@ -509,10 +583,12 @@ def main():
             "cpu_baseline": cpu,
             "other_workloads": [
                 {k: r[k] for k in ("workload", "knn_order", "worlds", "agent_steps_per_s", "padded_agent_steps_per_s", "ms_per_step",
-                                   "ms_per_step_events", "gc_ms_in_timed_stretches", "spin_up_steps", "overlapped_kernels", "kernels_sum_us", "live_agents_per_rank", "road_entities_per_rank",
+                                   "ms_per_step_events", "gc_ms_in_timed_stretches", "spin_up_steps", "overlapped_kernels", "kernels_sum_us", "live_agents_per_rank", "live_agents_with_roads_in_reach", "road_entities_per_rank",
                                    "roofline", "kernels", "other_rooflines")}
                 for r in results[1:]],
             "init_seconds": primary["init_seconds"],
+            "live_agents_per_rank": primary["live_agents_per_rank"],
+            "live_agents_with_roads_in_reach": primary["live_agents_with_roads_in_reach"],
         }
         print(json.dumps(line), flush=True)
         if args.headless:

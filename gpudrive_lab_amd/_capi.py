@@ -5,7 +5,15 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.environ.get("GPUDRIVE_AMD_LIB") or os.path.join(_HERE, "libgpudrive_amd.so")  # override: developer experiments only
+_SO = os.path.join(_HERE, "libgpudrive_amd.so")
+# Developer experiments only (tools/build_expt.sh writes them to build/expt/, outside this package): another build of the
+# library is loaded only when GPUDRIVE_DEV=1 says so as well -- a stray GPUDRIVE_AMD_LIB alone must never make a bench or
+# a test run a diagnostic build.
+if os.environ.get("GPUDRIVE_AMD_LIB"):
+    if os.environ.get("GPUDRIVE_DEV") != "1":
+        raise ImportError("GPUDRIVE_AMD_LIB is set but GPUDRIVE_DEV=1 is not: refusing to load a developer build of the "
+                          "library (unset GPUDRIVE_AMD_LIB, or set GPUDRIVE_DEV=1 for an experiment)")
+    _SO = os.environ["GPUDRIVE_AMD_LIB"]
 _LIB = None
 
 GD_OK = 0

@@ -129,27 +129,43 @@ struct gd_sim {
     bool rk_possible = false;  // reference order, k-NN, not switched off: a batch may take the rank replay
     bool rk_alloc = false;     // its buffers exist
 
-    void ensure_rank_buffers() {
-        if (rk_alloc) return;
+    // 5.7 KB per agent slot for ALL W * A slots (0.37 GB at 1024 x 64, 1.5 GB at 4096 x 64), allocated when a batch first takes
+    // the rank replay and kept for the life of the simulator.  The path is a scheduling choice, never a result: when the
+    // device cannot give the memory, what was allocated is returned, the batch stays on k_map_obs (same rows) and the
+    // rank replay is not tried again for this simulator.
+    bool ensure_rank_buffers() {
+        if (rk_alloc) return true;
         const size_t WA = static_cast<size_t>(W) * A;
-        d.rk_E = alloc_internal<uint16_t>(WA * GD_RANK_CAP + 64);  // the replay prefetches up to 24 entries past a row
-        d.rk_spc = alloc_internal<uint16_t>(WA * GD_RANK_CAP);
-        d.rk_heap = alloc_internal<uint32_t>(WA * GD_RANK_HEAP_DW);
-        d.rk_cpe = alloc_internal<uint16_t>(WA * GD_RANK_NCP);
-        d.rk_n = alloc_internal<int32_t>(WA);
-        d.rk_fallback = alloc_internal<int32_t>(WA / 32);
-        d.rk_streak = alloc_internal<int32_t>(WA / 32);
-        d.cp_road = alloc_internal<uint16_t>(2 * WA * GD_RANK_NCP);
-        d.cp_T = alloc_internal<float>(2 * WA * GD_RANK_NCP);
-        d.cp_hdr = alloc_internal<float4>(2 * WA);
-        d.rk_words = alloc_internal<uint32_t>(WA * GD_RANK_NCH);
-        d.rk_tl = alloc_internal<float>(WA);
-        d.rk_hist = alloc_internal<int32_t>(544);
-        d.rk_ticket = alloc_internal<int32_t>(WA);
-        d.rk_order = alloc_internal<int32_t>(WA);
-        d.rk_list = alloc_internal<int32_t>(8 * WA);
-        d.road_bbox = alloc_internal<float4>(W);
+        const size_t first = internal.size();
+        try {
+            d.rk_E = alloc_internal<uint16_t>(WA * GD_RANK_CAP + 64);  // the replay prefetches up to 24 entries past a row
+            d.rk_spc = alloc_internal<uint16_t>(WA * GD_RANK_SPL);
+            d.rk_kt = alloc_internal<float>(WA * GD_RANK_KT);
+            d.rk_heap = alloc_internal<uint32_t>(WA * GD_RANK_HEAP_DW);
+            d.rk_cpe = alloc_internal<uint16_t>(WA * GD_RANK_NCP);
+            d.rk_n = alloc_internal<int32_t>(WA);
+            d.rk_fallback = alloc_internal<int32_t>(WA / 32);
+            d.rk_streak = alloc_internal<int32_t>(WA / 32);
+            d.cp_road = alloc_internal<uint16_t>(2 * WA * GD_RANK_NCP);
+            d.cp_T = alloc_internal<float>(2 * WA * GD_RANK_NCP);
+            d.cp_hdr = alloc_internal<float4>(2 * WA);
+            d.rk_words = alloc_internal<uint32_t>(WA * GD_RANK_NCH);
+            d.rk_tl = alloc_internal<float>(WA);
+            d.rk_hist = alloc_internal<int32_t>(544);
+            d.rk_ticket = alloc_internal<int32_t>(WA);
+            d.rk_order = alloc_internal<int32_t>(WA);
+            d.rk_list = alloc_internal<int32_t>(8 * WA);
+            d.road_bbox = alloc_internal<float4>(W);
+        } catch (const HipError &) {
+            (void)hipGetLastError();
+            for (size_t k = first; k < internal.size(); k++) (void)hipFree(internal[k]);
+            internal.resize(first);
+            rk_possible = false;
+            d.rk_on = 0;
+            return false;
+        }
         rk_alloc = true;
+        return true;
     }
     bool timing = false;
     std::vector<EventPair> ev_pool[gd::KERNEL_TIMED];
@@ -613,10 +629,7 @@ struct gd_sim {
                 const int R = road_off[w + 1] - road_off[w];
                 if (R >= std::max(d.rk_min_roads, GD_MAP_OBS_K) && R <= d.rk_max_roads) d.rk_on = 1;
             }
-            if (d.rk_on) {
-                ensure_rank_buffers();
-                reset_rank_state();
-            }
+            if (d.rk_on && ensure_rank_buffers()) reset_rank_state();
         }
         {
             // one BEV workgroup per LIVE agent: a workgroup that only finds out it has no agent still has to be given
@@ -737,7 +750,7 @@ struct gd_sim {
         HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemset(d.rk_fallback, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
         HIP_CHECK(hipMemset(d.rk_streak, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
-        HIP_CHECK(hipMemset(d.rk_hist, 0, sizeof(int32_t) * 544));  // bin counts, the lists of ranked agents: empty
+        HIP_CHECK(hipMemset(d.rk_hist, 0, sizeof(int32_t) * GD_RANK_AUDIT));  // bin counts, the lists of ranked agents: empty (the audit counter behind them keeps counting)
     }
 
     void do_reset(const std::vector<int32_t> &flags) {
@@ -918,6 +931,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.resp = s->alloc_internal<int32_t>(WA);
         d.sel_idx = s->alloc_internal<uint16_t>(static_cast<size_t>(WA) * GD_MAP_OBS_K);
         d.sel_hdr = s->alloc_internal<float4>(static_cast<size_t>(WA) * 2);
+        d.sel_slot = s->alloc_internal<uint8_t>(static_cast<size_t>(WA) * GD_MAP_OBS_K);
         d.reset_flags = s->alloc_internal<int32_t>(W);
         d.rebuilt_flags = s->alloc_internal<int32_t>(W);
         d.any_reset = s->alloc_internal<int32_t>(1);
@@ -1112,6 +1126,17 @@ int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
 #else
     constexpr int32_t kLastStat = 7;
 #endif
+    if (s && out && which == 21) {  // bounds audit of the rank path (engine.hpp GD_RANK_AUDIT): violations since the buffers exist
+        *out = 0;
+        if (s->rk_alloc) {
+            int32_t v = 0;
+            (void)hipStreamSynchronize(s->stream);
+            if (hipMemcpy(&v, s->d.rk_hist + GD_RANK_AUDIT, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(GD_ERR_DEVICE, "gd_stat: reading the audit counter failed");
+            *out = v;
+        }
+        return GD_OK;
+    }
     if (!s || !out || which < 0 || which > kLastStat) return fail(GD_ERR_INVALID, "gd_stat: bad argument");
 #if defined(GD_DIAG) || defined(GD_CLOCKS)
     if (which >= 8) {  // 8 = most crowded ranking bucket (-DGD_DIAG, GPUDRIVE_RANK_DBG=9), 10..17 = clock ticks / 256 per phase of

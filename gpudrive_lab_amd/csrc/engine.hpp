@@ -16,6 +16,15 @@
 #define GD_RANK_NCP 40
 #define GD_RANK_HEAP_DW 104
 #define GD_RANK_NCH 320  // candidate words per agent: 32 roads each, kMaxRoadEntityCount = 10,000
+#define GD_RANK_SPL 256  // sorted slots whose road index k_knn_rank hands on: the K elements the heap ends with have the K smallest
+                         // keys, i.e. fewer than K candidates below them and at most 31 equal ones before them: slot < K + 31
+#define GD_RANK_KT 84    // floats per agent of the key table: the candidates' key at every 16th sorted slot (CAP / 16 entries), the
+                         // largest key behind them; padded to 16 bytes
+// rk_hist[GD_RANK_AUDIT]: bounds audit of the rank path (product build too).  Every index that the rank kernels derive from
+// data another kernel wrote (a rank turned into a table slot, a ticket into a place of the replay order, a list cursor) is
+// checked against its array before it is used; a violation is counted here and the index clamped into the array, so that
+// a broken invariant shows up as a failed test (gd_stat 21 must read 0), never as an access outside an allocation.
+#define GD_RANK_AUDIT 536
 
 // Phase switches for timing experiments exist only in diagnostic builds (-DGD_DIAG); in the product library the
 // condition is the constant false and the compiler drops the code.
@@ -69,7 +78,9 @@ struct DevSim {
     // road selection scratch: what k_map_obs / k_map_obs_set hand to k_map_rows
     uint16_t *sel_idx;    // [W][A][K] road index (within the world) of every selected slot, in output order
     float4 *sel_hdr;      // [W][A][2] per agent for k_map_rows: (x, y, qw, qz) and, as int bits, (selected rows, first road of the
-                          // world, 0, 0); the count is -1 where this launch selected nothing (padding agents)
+                          // world, permuted, 0); the count is -1 where this launch selected nothing (padding agents)
+    uint8_t *sel_slot;    // [W][A][K] permuted != 0 only: sel_idx lists the selected roads in ASCENDING road index (what the
+                          // gathers like) and entry q belongs in output row sel_slot[q]; permuted == 0: entry q is row q
     // per world flags
     int32_t *reset_flags, *rebuilt_flags;
     int32_t *any_reset;    // one int: k_episode_step raised at least one reset flag in this step
@@ -105,10 +116,11 @@ struct DevSim {
     int rk_min_roads;  // worlds with fewer roads are selected by k_map_obs (the rank path's fixed costs do not pay there)
     int rk_dbg;  // -DGD_DIAG builds only: k_knn_rank stops after phase n (timing only; results are wrong)
     uint16_t *rk_E;        // [W][A][CAP] rank of every candidate, candidate (= road) order
-    uint16_t *rk_spc;      // [W][A][CAP] sorted slot -> road index
+    uint16_t *rk_spc;      // [W][A][GD_RANK_SPL] sorted slot -> road index, the first GD_RANK_SPL slots
+    float *rk_kt;          // [W][A][GD_RANK_KT] key at sorted slot 16 j (16 j < n), then the largest key at j = ceil(n / 16)
     uint32_t *rk_heap;     // [W][A][GD_RANK_HEAP_DW] the replayed heap array as rank pairs
     uint16_t *rk_cpe;      // [W][A][NCP] rank on top of the heap at every checkpoint of this selection
-    int32_t *rk_hist;      // [544] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path, selections so far; [514..526] counters of developer builds; [528..535] entries of rk_list
+    int32_t *rk_hist;      // [544] replay order: 256 bin counts, 256 bin starts, the number of agents on the rank path, selections so far; [514..526] counters of developer builds; [528..535] entries of rk_list; [536] bounds audit (GD_RANK_AUDIT)
     int32_t *rk_ticket;    // [W][A] bin << 20 | place inside the bin (bit 30: fell back after taking it); -1 = not on the rank path this step; < -1: why
     int32_t *rk_order;     // [W][A] agents on the rank path, most candidates first
     int32_t *rk_list;      // [8][W][A] agents on the rank path, one list per XCD that scanned them (counts: rk_hist[528..535])

@@ -484,40 +484,53 @@ __device__ __forceinline__ void order_waves(const DevSim &d, int count, unsigned
     __syncthreads();
 }
 
+// A workgroup writes the K rows of ROWS_AB consecutive agent slots: one contiguous block of the tensor (ROWS_AB x 7200
+// bytes).  Entry q of an agent's selection is gathered by thread q and its row is put where the selection kernel says it
+// belongs (sel_slot; engine.hpp): the rank path hands its roads over in ASCENDING road index -- neighbouring threads then
+// gather neighbouring 32-byte records (the nearest roads come in runs along their polylines) instead of the heap's order
+// (136 -> us for the same 472 MB at 1024 x 64; set order, ascending by construction, always ran at 82) -- and the
+// order only has to exist where the rows are stored.
+constexpr int ROWS_AB = 5;
 template <int A_T>
 __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
-    constexpr int U = GD_ROWS_PER_THREAD;  // rows per thread (256 apart): independent load chains in flight
-    constexpr int RB = 256 * U;   // rows per workgroup: consecutive, so their 36-byte rows are one contiguous 18 KB block
+    constexpr int U = GD_ROWS_PER_THREAD;  // entries per thread (256 apart): independent load chains in flight
+    constexpr int RB = ROWS_AB * K;        // rows per workgroup
+    static_assert(256 * U >= RB && (RB * 9) % 4 == 0 && (K * 9) % 4 == 0, "every entry has a thread; whole 16-byte pieces per agent");
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     __shared__ __attribute__((aligned(16))) float s_rows[RB * 9];
     static_assert(RB * 9 >= 513, "order_waves borrows the row buffer");
     if (blockIdx.x == 0 && d.knn_order != GD_KNN_SET_ORDER)
         order_waves<256>(d, d.W * (A_T / AW), reinterpret_cast<unsigned int *>(s_rows));
-    const size_t rows = (size_t)d.W * A_T * K;
-    // Which rows a workgroup takes: workgroup b runs on XCD b % 8, and the XCDs take eighths of the tensor, so that a world's
-    // road records (128 KB on the bench scene, gathered in heap order) are fetched into one L2 instead of all eight
+    const size_t agents = (size_t)d.W * A_T;
+    // Which agents a workgroup takes: workgroup b runs on XCD b % 8, and the XCDs take eighths of the tensor, so that a world's
+    // road records (128 KB on the bench scene) are fetched into one L2 instead of all eight
     const unsigned int per_xcd = gridDim.x >> 3;  // (the grid is a multiple of 8 workgroups)
-    const size_t base = (size_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * RB;
-    if (base >= rows) return;
-    // the agent's header (pose, count, first road: written by the selection kernel) and the slot's road index come in one
-    // round trip, the road's 32-byte record in a second one
+    const size_t a0 = (size_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * ROWS_AB;
+    if (a0 >= agents) return;
+    // the agent's header (pose, count, first road, permuted: written by the selection kernel), the entry's road index and
+    // its row come in one round trip, the road's 32-byte record in a second one
     bool on[U], in[U];
-    int r[U];
+    int r[U], dst[U];
     float4 pose[U];
+    __shared__ unsigned char s_on[ROWS_AB];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const size_t p = base + threadIdx.x + (size_t)u * 256;
-        on[u] = p < rows;
-        const size_t pc = on[u] ? p : 0;
-        const size_t wa = pc / K;
-        const int s = (int)(pc - wa * K);
+        const int p = threadIdx.x + u * 256;
+        const int al = min(p / K, ROWS_AB - 1);
+        const int q = p - al * K;
+        const size_t wa = min(a0 + al, agents - 1);
         pose[u] = d.sel_hdr[wa * 2];
         const float4 meta = d.sel_hdr[wa * 2 + 1];
         const int cnt = __float_as_int(meta.x);
-        r[u] = __float_as_int(meta.y) + (int)d.sel_idx[pc];
-        on[u] = on[u] && cnt >= 0;  // rows of padding agents are written at reset (k_init_padding_rows)
-        in[u] = s < cnt;
-        if (!in[u]) r[u] = 0;
+        const bool permuted = __float_as_int(meta.z) != 0;
+        const size_t e = wa * K + min(q, K - 1);
+        const int idx = (int)d.sel_idx[e];
+        const int slot = (int)d.sel_slot[e];
+        on[u] = p < RB && a0 + al < agents && cnt >= 0;  // rows of padding agents are written at reset (k_init_padding_rows)
+        in[u] = q < cnt;
+        r[u] = in[u] ? __float_as_int(meta.y) + idx : 0;
+        dst[u] = al * K + ((in[u] && permuted) ? min(slot, K - 1) : q);
+        if (p < RB && q == 0) s_on[al] = on[u] ? 1 : 0;
     }
     float4 q0[U], q1[U];
 #pragma unroll
@@ -526,31 +539,22 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
         q1[u] = d.road_rec[(size_t)r[u] * 2 + 1];
     }
     // The block's rows are assembled in LDS (row stride 9 floats: conflict-free) and leave as whole 16-byte pieces in
-    // row-major order, one piece per thread and pass; rows that must not be written (padding agents, beyond the
-    // tensor) are marked and their pieces skipped.  Streaming (nt) stores: the rows are written once and not read
-    // again by the step, and must not push the road and agent arrays out of L2 / Infinity Cache.
-    __shared__ unsigned char s_on[RB];
+    // row-major order, one piece per thread and pass; an agent's rows are 450 pieces, so the pieces of agents that must not
+    // be written (padding agents, beyond the tensor) are skipped whole.  Streaming (nt) stores: the rows are written once
+    // and not read again by the step, and must not push the road and agent arrays out of L2 / Infinity Cache.
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const int lr = threadIdx.x + u * 256;
-        s_on[lr] = on[u] ? 1 : 0;
-        road_row(s_rows + lr * 9, in[u], d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST, pose[u].x, pose[u].y, pose[u].z, pose[u].w,
-                 q0[u], q1[u]);
+        if (threadIdx.x + u * 256 < RB)
+            road_row(s_rows + dst[u] * 9, in[u], d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST, pose[u].x, pose[u].y, pose[u].z,
+                     pose[u].w, q0[u], q1[u]);
     }
     __syncthreads();
-    float *out = d.agent_map + base * 9;  // base * 36 bytes: 16-byte aligned (RB * 36 is a multiple of 16)
+    float *out = d.agent_map + a0 * (size_t)(K * 9);  // a0 * 7200 bytes: 16-byte aligned
     typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int PPA = K * 9 / 4;  // pieces per agent
     for (int q = threadIdx.x; q < RB * 9 / 4; q += 256) {
-        const int r_lo = (q * 4) / 9, r_hi = (q * 4 + 3) / 9;  // the piece touches at most two rows
-        const bool a_on = s_on[r_lo] != 0, b_on = s_on[r_hi] != 0;
-        const f4 v = *reinterpret_cast<const f4 *>(s_rows + q * 4);
-        if (a_on && b_on) {
-            __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + (size_t)q * 4));
-        } else if (a_on || b_on) {  // a piece shared with a row that must stay untouched: element by element
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (s_on[(q * 4 + e) / 9]) __builtin_nontemporal_store(v[e], out + (size_t)q * 4 + e);
-        }
+        if (s_on[q / PPA] != 0)
+            __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + (size_t)q * 4));
     }
 }
 
@@ -588,7 +592,12 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
     // after the rank replay (map_obs_rank.hip) only the groups that could not take it are selected here
     const bool rank_path = d.rk_on != 0 && d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
     if (rank_path) {
-        if (d.rk_fallback[slot] == 0) return;
+        if (d.rk_fallback[slot] == 0) {
+            // selected by the rank replay: nothing to do here, and nothing to schedule first next time (order_waves would
+            // otherwise keep dealing this group the cycles of its last fallback)
+            if (lane == 0) d.wave_cost[slot] = 0u;
+            return;
+        }
     }
     const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
     const int n = d.shape[w * 2 + 0];
@@ -1273,8 +1282,8 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs<64>), grid, dim3(64), 0, st, d);
         else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);
     }
-    const size_t rows = (size_t)d.W * d.A * K;
-    const dim3 rgrid((unsigned int)((rows + 256 * GD_ROWS_PER_THREAD - 1) / (256 * GD_ROWS_PER_THREAD) + 7) / 8 * 8);
+    const size_t agents = (size_t)d.W * d.A;
+    const dim3 rgrid((unsigned int)((agents + ROWS_AB - 1) / ROWS_AB + 7) / 8 * 8);
     if (d.A == 64) hipLaunchKernelGGL((k_map_rows<64>), rgrid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((k_map_rows<128>), rgrid, dim3(256), 0, st, d);
 }

@@ -42,12 +42,15 @@ namespace {
 constexpr int K = GD_MAP_OBS_K;
 constexpr int CAP = GD_RANK_CAP;   // candidates per agent
 constexpr int NCP = GD_RANK_NCP;   // checkpoints per agent
+constexpr int SPL = GD_RANK_SPL;   // sorted slots handed to k_knn_finish
+constexpr int KT = GD_RANK_KT;     // key table entries per agent
 constexpr int TILE = 32;           // candidates between checkpoints
 constexpr int NB = 1280;           // ranking buckets
 constexpr int NLIN = 768;          // of which linear in the key (up to 1.5 x the previous K-th key); the other 512 take
                                    // the eight octaves above that, 64 each: about one candidate per bucket on either side
 static_assert(K + (NCP - 1) * TILE >= CAP, "a checkpoint slot for every tile of candidates");
 static_assert(CAP % 64 == 0 && NB % 128 == 0 && CAP < 2047, "geometry; less + 1 fits 11 bits");
+static_assert(SPL >= K + 31 && SPL <= CAP && KT >= CAP / 16 + 1, "every slot the finish looks up; an entry per 16 slots + the last");
 constexpr int RK_FAR = 1 << 30;    // rk_n: no road of the world can be within the agent's radius
 constexpr int RK_TIES = 1 << 30;   // rk_ticket: the agent took its place in the replay order, then fell back (equal keys)
 
@@ -85,6 +88,44 @@ __device__ __forceinline__ int wave_max(int v) {
 __device__ __forceinline__ float wave_max_nonneg(float f) { return __int_as_float(wave_max(__float_as_int(f))); }
 __device__ __forceinline__ float wave_min_nonneg(float f) { return __int_as_float(~wave_max(~__float_as_int(f))); }
 __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
+
+// Scratch rows that one kernel writes once and the next reads once (candidate words, ranks, heap arrays, tables): streaming
+// (nt) accesses, so that they take no room from what the step reads again and again (the road arrays, the pose planes).
+#ifndef GD_NT_SCAN_STORE
+#define GD_NT_SCAN_STORE 0
+#endif
+#ifndef GD_NT_REPLAY_LOAD
+#define GD_NT_REPLAY_LOAD 1
+#endif
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void stream_store(T v, T *p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ uint4 stream_load(const uint4 *p) {
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stream_store(uint4 v, uint4 *p) {
+    u4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<u4v *>(p));
+}
+__device__ __forceinline__ uint2 stream_load(const uint2 *p) {
+    const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(p));
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void stream_store(uint2 v, uint2 *p) {
+    u2v t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<u2v *>(p));
+}
+
+// bounds audit (engine.hpp GD_RANK_AUDIT): `idx` must lie in [0, size); counts the violation and returns an index that does
+__device__ __forceinline__ int audited(const DevSim &d, int idx, int size) {
+    if ((unsigned int)idx < (unsigned int)size) return idx;
+    atomicAdd(&d.rk_hist[GD_RANK_AUDIT], 1);
+    return idx < 0 ? 0 : size - 1;
+}
 
 // key comparison on ranks: key(a) < key(b)  <=>  (a >> 5) < (b >> 5)  <=>  (a | 31) < b.  0 is "below everything".
 __device__ __forceinline__ bool rank_lt(unsigned int a, unsigned int b) { return (a | 31u) < b; }
@@ -229,14 +270,19 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
 #pragma unroll
             for (int it = 0; it < TB; it++) {
                 const int ag = it * 8 + (lane >> 3), k = lane & 7;
+#if GD_NT_SCAN_STORE
+                if (c_first + k < nch && s_ncp[ag] > 0) stream_store(s_tr[wave][k][ag], words + (size_t)ag * GD_RANK_NCH + c_first + k);
+#else
                 if (c_first + k < nch && s_ncp[ag] > 0) words[(size_t)ag * GD_RANK_NCH + c_first + k] = s_tr[wave][k][ag];
+#endif
             }
             wave_sync();
         }
     }
     if (wave == 0 && ranked != 0ull) {
         list_base = __builtin_amdgcn_readfirstlane(list_base);
-        if (ncp > 0) d.rk_list[(size_t)(blockIdx.x & 7) * WA + list_base + __popcll(ranked & ((1ull << lane) - 1ull))] = (int)i;
+        if (ncp > 0)
+            d.rk_list[(size_t)(blockIdx.x & 7) * WA + audited(d, list_base + __popcll(ranked & ((1ull << lane) - 1ull)), (int)WA)] = (int)i;
     }
 }
 
@@ -270,6 +316,12 @@ struct RankIn {
 // A value at a wave-uniform address that this kernel does not change, read through the scalar cache.  As vector loads the
 // chain list -> agent -> state / pose waited, at each link, for every store the wave had issued for the previous agent
 // (vector memory operations are counted in order): a fifth of the kernel.
+// INVARIANT (nothing enforces it but the call sites below): the scalar cache is not coherent with this kernel's own vector
+// stores, so an address read through here must never be read AFTER any wave of the same launch has written it.  What is
+// read this way: arrays written by EARLIER kernels only (rk_list, rk_hist[528..], rk_tl, road_off, the pose planes: the
+// scalar cache is invalidated at every kernel boundary), and rk_n[i] -- which this kernel does rewrite, but only the wave
+// that ranks agent i writes rk_n[i], and it reads it (rank_fetch) before it writes it (end of rank_agent); a cache line
+// shared with another agent's already rewritten entry may be stale for THAT entry, which this wave never looks at.
 template <typename T>
 __device__ __forceinline__ T uniform_load(const T *p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
@@ -290,7 +342,7 @@ __device__ __forceinline__ RankIn rank_fetch(const DevSim &d, const int *list, i
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
         const int c = k * 64 + lane;
-        in.wd[k] = (in.state == 1 && c < nch) ? words[c] : 0u;
+        in.wd[k] = (in.state == 1 && c < nch) ? stream_load(words + c) : 0u;
     }
     return in;
 }
@@ -339,7 +391,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     int nin = K;
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
-        if (k * 64 >= nch || nin > CAP) break;  // wave-uniform
+        if (k * 64 >= nch || nin >= CAP) break;  // wave-uniform
         const int c = k * 64 + lane;
         unsigned int wd = in.wd[k];
         if (k == 0) wd = c < K / 32 ? 0u : (c == K / 32 ? wd & ~((1u << (K % 32)) - 1u) : wd);
@@ -350,13 +402,16 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         const int incl = wave_incl_scan(pc);
         int pos = nin + incl - pc;
         nin += __builtin_amdgcn_readlane(incl, 63);
-        if (nin > CAP) break;  // wave-uniform
+        if (nin >= CAP) break;  // wave-uniform
         while (wd) {
             L.cidx[pos++] = (unsigned short)((c << 5) + __ffs(wd) - 1);
             wd &= wd - 1u;
         }
     }
-    if (nin > CAP) {
+    // (CAP itself counts as too many: the sorted key array ends in one +inf entry that reads past a bucket's end run into --
+    // with exactly CAP candidates there was no room for it and the clamp that stood in for it re-read the LAST entry of
+    // the last bucket, which is not necessarily its largest: a candidate of that bucket could count a smaller key twice)
+    if (nin >= CAP) {
         if (lane == 0) {
             d.rk_n[i] = 0;
             d.rk_ticket[i] = -3;  // more candidates than the buffer holds
@@ -522,11 +577,13 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     // candidates that met their own key more than once (equal keys, rare) get their place among those afterwards.
     unsigned int e[NG];
     unsigned int eqmask = 0u;  // bit g: candidate g of this lane shares its key with another candidate
+    float *const kt_row = d.rk_kt + (size_t)i * GD_RANK_KT;
+    if (lane == 0) kt_row[(nin + 15) >> 4] = kmax_seen;  // behind the last multiple of 16: the largest key
     constexpr int U = 4, M = 8, STEP = 4;
     // A read past the end of the own bucket meets keys of later buckets, which are larger (the bucket function is monotone)
     // and so count neither as smaller nor as equal: no bounds test per member.  Past the last candidate it meets +inf.
-    const int lim = min(nin, CAP - 1);  // (nin == CAP: the clamp re-reads the largest key, which is not smaller than any)
-    if (lane == 0 && nin < CAP) L.s.skey[nin] = __builtin_inff();
+    const int lim = nin;  // < CAP
+    if (lane == 0) L.s.skey[nin] = __builtin_inff();
     wave_sync();
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += U) {
@@ -573,8 +630,13 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            eqmask |= (eq[u] > 1) & ((g0 + u) * 64 + lane < nin) ? 1u << (g0 + u) : 0u;  // (a candidate meets itself once)
+            const bool on = (g0 + u) * 64 + lane < nin;
+            eqmask |= ((eq[u] > 1) & on) ? 1u << (g0 + u) : 0u;  // (a candidate meets itself once)
             e[g0 + u] = (unsigned int)((less[u] + 1) << 5);
+            // the key table for k_knn_finish: this key sits at the sorted slots [less, less + eq); whoever holds slot 16 j
+            // writes entry j (candidates with equal keys write the same value)
+            const int j = (less[u] + 15) >> 4;
+            if (on && (j << 4) < less[u] + eq[u]) kt_row[j] = key[g0 + u];
         }
     }
     int too_many_ties = 0;
@@ -614,28 +676,27 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         return;
     }
     // (rows through scalar base addresses and unsigned 32-bit lane offsets: see `uni` above)
-    unsigned short *const E_row = d.rk_E + (size_t)i * CAP, *const spc_row = d.rk_spc + (size_t)i * CAP;
+    // The slot -> road table goes on for its first SPL slots only: the K elements the replayed heap ends with are the K
+    // smallest keys (slot < K + 31 with equal keys), and that is all k_knn_finish looks up by slot -- the checkpoints'
+    // K-th keys come from the key table above (round 3 wrote all CAP slots, 2.5 KB per agent, and k_knn_finish fetched the
+    // whole row back for 240 scattered 2-byte reads)
+    unsigned short *const E_row = d.rk_E + (size_t)i * CAP;
     const unsigned int ulane = (unsigned int)lane;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         if (g * 64 < nin) {  // wave-uniform
             if (g * 64 + lane < nin) {
-                E_row[g * 64u + ulane] = (unsigned short)e[g];
-                L.spc[(int)(e[g] >> 5) - 1 + (int)(e[g] & 31u)] = (unsigned short)(ci[g] & 0xffff);
+                stream_store((unsigned short)e[g], E_row + (g * 64u + ulane));
+                const int slot = (int)(e[g] >> 5) - 1 + (int)(e[g] & 31u);
+                if (slot < SPL) L.spc[slot] = (unsigned short)(ci[g] & 0xffff);
             }
         }
     }
     wave_sync();
-#pragma unroll
-    for (int g0 = 0; g0 < NG; g0 += GQ) {
-        if (g0 * 64 < nin) {  // wave-uniform
-            unsigned short v[GQ];
-#pragma unroll
-            for (int u = 0; u < GQ; u++) v[u] = L.spc[(g0 + u) * 64 + lane];
-#pragma unroll
-            for (int u = 0; u < GQ; u++)
-                if ((g0 + u) * 64 + lane < nin) spc_row[(g0 + u) * 64u + ulane] = v[u];
-        }
+    {
+        static_assert(SPL == 256, "four slots per lane");
+        const uint2 v = reinterpret_cast<const uint2 *>(L.spc)[lane];
+        stream_store(v, reinterpret_cast<uint2 *>(d.rk_spc + (size_t)i * SPL) + ulane);
     }
     if (lane == 0) {
         d.rk_n[i] = nin | (nle << 16) | (has_tie ? 1 << 28 : 0);
@@ -731,7 +792,7 @@ __global__ __launch_bounds__(256) void k_knn_order(DevSim d) {
     const int i = d.live_list[t];
     const int ticket = d.rk_ticket[i];
     if (ticket < 0) return;  // not on the rank path
-    d.rk_order[d.rk_hist[256 + ((ticket >> 20) & 255)] + (ticket & 0xfffff)] = i;
+    d.rk_order[audited(d, d.rk_hist[256 + ((ticket >> 20) & 255)] + (ticket & 0xfffff), d.W * d.A)] = i;
 }
 
 __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
@@ -762,7 +823,7 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
         }
 #pragma clang loop unroll(disable)
         for (int k = 0; k < K / 8; k++) {
-            const uint4 v = on ? src[k] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 v = on ? stream_load(src + k) : make_uint4(0u, 0u, 0u, 0u);
             const unsigned int wd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -812,8 +873,8 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
     const uint4 *blocks = reinterpret_cast<const uint4 *>(E + K);  // K * 2 bytes: 16-byte aligned
-    uint4 cur = on ? blocks[0] : make_uint4(0u, 0u, 0u, 0u);
-    uint4 nxt = on ? blocks[1] : make_uint4(0u, 0u, 0u, 0u);
+    uint4 cur = on ? (GD_NT_REPLAY_LOAD ? stream_load(blocks) : blocks[0]) : make_uint4(0u, 0u, 0u, 0u);
+    uint4 nxt = on ? (GD_NT_REPLAY_LOAD ? stream_load(blocks + 1) : blocks[1]) : make_uint4(0u, 0u, 0u, 0u);
     // Two copies of the loop.  When none of the wave's agents has two candidates with one key (k_knn_rank reports it), every
     // rank's tie field is 0, a plain integer compare IS the key compare, "the larger child" is a max and the values along
     // the pop's path and the push's chain are medians of three (the moved children are non-increasing down the path, the
@@ -839,7 +900,7 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
         for (int p0 = K; p0 < nmax; p0 += 8) {
           uint4 w8 = cur;
           cur = nxt;
-          nxt = blocks[((p0 - K) >> 3) + 2];  // may run past this agent's candidates: the array ends in slack.  Every lane, idle
+          nxt = GD_NT_REPLAY_LOAD ? stream_load(blocks + ((p0 - K) >> 3) + 2) : blocks[((p0 - K) >> 3) + 2];  // may run past this agent's candidates: the array ends in slack.  Every lane, idle
                                               // ones too (they read row 0): a merge with the old value would wait for the data
 #pragma clang loop unroll(disable)
           for (int p = p0; p < min(p0 + 8, nmax); p++) {
@@ -970,13 +1031,16 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
             v.y = j + 1 <= K / 2 ? H.pair(j + 1) : 0u;
             v.z = j + 2 <= K / 2 ? H.pair(j + 2) : 0u;
             v.w = j + 3 <= K / 2 ? H.pair(j + 3) : 0u;
-            *reinterpret_cast<uint4 *>(out + j) = v;
+            stream_store(v, reinterpret_cast<uint4 *>(out + j));
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_knn_finish
+// k_knn_finish: one wave per agent.  Heap array (ranks) -> road indices, radiusFilter, the checkpoints' K-th keys, and the
+// hand-over to k_map_rows: the selected roads in ASCENDING road index with the output row each belongs in.
+// Everything it reads is a contiguous piece of the agent's scratch rows: the heap (416 B), the first SPL sorted slots
+// (512 B), the key table (336 B), the checkpoint ranks (80 B).
 // ------------------------------------------------------------------------------------------------------------------
 template <int A_T>
 __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
@@ -985,12 +1049,27 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     const int li = blockIdx.x * 4 + wave;
     if (li >= d.live_count) return;
     const int i = d.live_list[li];
-    if (d.rk_fallback[i / 32] != 0) return;  // k_map_obs selects for this group
-    const int packed = d.rk_n[i];
+    // Everything the wave reads from global memory depends on `i` alone and every address is valid for any agent slot (stale
+    // at worst): requested together, before the first branch looks at any of it -- the kernel is a chain of memory round
+    // trips with little arithmetic in between (round 3's version asked for flag, count, pose, heap and table one after the
+    // other, each behind a branch on the one before)
+    constexpr int NP = (K + 63) / 64;
     const int w = i / A_T;
-    const int r0 = d.road_off[w];
+    const int fell_back = d.rk_fallback[i / 32];
+    const int packed = d.rk_n[i];
+    const int r0 = d.road_off[w], r1 = d.road_off[w + 1];
     const float ex = d.px[i], ey = d.py[i];
     const float qw = d.qw[i], qz = d.qz[i];
+    const uint32_t steps_left = d.steps[i];
+    const unsigned int *hp = d.rk_heap + (size_t)i * GD_RANK_HEAP_DW;
+    unsigned int hpair[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) hpair[ps] = stream_load(hp + min((ps * 64 + lane + 1) >> 1, GD_RANK_HEAP_DW - 1));
+    static_assert(SPL == 256, "four slots per lane");
+    const uint2 spc4 = stream_load(reinterpret_cast<const uint2 *>(d.rk_spc + (size_t)i * SPL) + lane);
+    const unsigned int cp_e = d.rk_cpe[(size_t)i * NCP + min(lane, NCP - 1)];
+    const unsigned short cp_r = d.cp_road[(size_t)i * NCP + min(lane, NCP - 1)];
+    if (fell_back != 0) return;  // k_map_obs selects for this group
     if (packed == RK_FAR) {  // every road is beyond the radius: radiusFilter leaves nothing (src/knn.hpp:83-97, 156-157)
         if (lane == 0) {
             d.sel_hdr[(size_t)i * 2] = make_float4(ex, ey, qw, qz);
@@ -1001,15 +1080,28 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     }
     const int n = packed & 0xffff, nle = (packed >> 16) & 0xfff;
     if (n < K) return;
+    // the checkpoints' K-th keys (see below): the table entry is known as soon as the checkpoint's rank is
+    const int cp_slot = (int)(cp_e >> 5) - 1 + (int)(cp_e & 31u);
+    const int ncp = 1 + (n - K) / TILE;
+    float cp_t = 0.f;
+    if (lane < ncp) cp_t = d.rk_kt[(size_t)i * KT + min(max((cp_slot + 15) >> 4, 0), (n + 15) >> 4)];
+    __shared__ unsigned short s_spc[4][SPL];
     __shared__ unsigned short s_don[4][K];
+    __shared__ unsigned int s_bm[4][GD_RANK_NCH];      // one bit per road of the world: selected
+    __shared__ unsigned short s_wp[4][GD_RANK_NCH];    // selected roads below each bitmap word
+    __shared__ unsigned int s_sorted[4][K];            // ascending road index -> road | output row << 16
     unsigned short *don = s_don[wave];
-    const unsigned int *hp = d.rk_heap + (size_t)i * GD_RANK_HEAP_DW;
-    const unsigned short *spc = d.rk_spc + (size_t)i * CAP;
+    unsigned int *bm = s_bm[wave];
     const unsigned long long lower = (1ull << lane) - 1ull;
+    {
+        reinterpret_cast<uint2 *>(s_spc[wave])[lane] = spc4;
+#pragma unroll
+        for (int k = 0; k < GD_RANK_NCH / 64; k++) bm[k * 64 + lane] = 0u;
+    }
+    wave_sync();
 
     // heap array -> road indices and in-radius flags (src/knn.hpp:88: length() <= radius; on ranks: fewer than `nle`
     // candidates have a smaller key)
-    constexpr int NP = (K + 63) / 64;
     int road[NP];
     bool inr[NP];
     unsigned long long fl[NP];
@@ -1020,10 +1112,12 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
         road[ps] = 0;
         inr[ps] = false;
         if (t < K) {
-            const unsigned int p2 = hp[g >> 1];
+            const unsigned int p2 = hpair[ps];
             const unsigned int e = (g & 1) ? p2 >> 16 : p2 & 0xffffu;
             const int less = (int)(e >> 5) - 1;
-            road[ps] = spc[less + (int)(e & 31u)];
+            // (a rank of 0 -- an element the replay never wrote -- would ask for slot -1; an element of the final heap has
+            // fewer than K keys below it and at most 31 equal ones before it)
+            road[ps] = s_spc[wave][audited(d, less + (int)(e & 31u), min(n, SPL))];
             inr[ps] = less < nle;
         }
         fl[ps] = __ballot(inr[ps]);
@@ -1053,25 +1147,58 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
             in_before += __popcll(fl[ps]);
         }
     }
+    // ---- hand-over: the m selected roads in ascending road index, each with its output row (k_map_rows gathers the
+    // 32-byte records in that order and puts the rows where they belong).  A bitmap of the world's roads, prefix counts
+    // per word, place = selected roads below. ----
+    const int R = r1 - r0;
 #pragma unroll
     for (int ps = 0; ps < NP; ps++) {
         const int t = ps * 64 + lane;
-        if (t < K) d.sel_idx[(size_t)i * K + t] = (unsigned short)road[ps];
+        if (t < m) atomicOr(&bm[audited(d, road[ps], R) >> 5], 1u << (road[ps] & 31));
     }
-    // the K-th distances at this selection's checkpoints: the exact key of the element whose rank was on top
+    wave_sync();
+    {
+        constexpr int WL = GD_RANK_NCH / 64;  // bitmap words per lane: lane l owns words l * WL ..
+        unsigned int own[WL];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < WL; k++) { own[k] = bm[lane * WL + k]; sum += __popc(own[k]); }
+        int run = wave_incl_scan(sum) - sum;
+#pragma unroll
+        for (int k = 0; k < WL; k++) { s_wp[wave][lane * WL + k] = (unsigned short)run; run += __popc(own[k]); }
+    }
+    wave_sync();
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+        const int t = ps * 64 + lane;
+        if (t < m) {
+            const int rd = min(max(road[ps], 0), R - 1);
+            const int place = (int)s_wp[wave][rd >> 5] + __popc(bm[rd >> 5] & ((1u << (rd & 31)) - 1u));
+            s_sorted[wave][audited(d, place, m)] = (unsigned int)rd | (unsigned int)t << 16;
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+        const int q = ps * 64 + lane;
+        if (q < K) {
+            const unsigned int v = q < m ? s_sorted[wave][q] : (unsigned int)q << 16;
+            d.sel_idx[(size_t)i * K + q] = (unsigned short)(v & 0xffffu);
+            d.sel_slot[(size_t)i * K + q] = (unsigned char)(v >> 16);
+        }
+    }
+    // the K-th distances at this selection's checkpoints: a key that is not below that of the element whose rank was on top
+    // -- from the key table, the candidates' key at the next multiple of 16 sorted slots (any upper bound of the K-th
+    // distance keeps the next selection's candidates a superset; this one is at most 15 ranks loose)
     // (a second copy is kept of the selection made at the start of an episode: a reset puts the agent back there)
-    const int ncp = 1 + (n - K) / TILE;
-    const bool at_start = d.steps[i] == (uint32_t)GD_EPISODE_LEN;
+    const bool at_start = steps_left == (uint32_t)GD_EPISODE_LEN;
     const size_t WA = (size_t)d.W * A_T;
     if (lane < ncp) {
-        const unsigned int e = d.rk_cpe[(size_t)i * NCP + lane];
-        const int r = spc[(int)(e >> 5) - 1 + (int)(e & 31u)];
-        const float2 xy = d.road_xy[r0 + r];
-        const float t = ego_dist2(ex, ey, qw, -qz, xy.x, xy.y);
-        d.cp_T[(size_t)i * NCP + lane] = t;
+        (void)audited(d, cp_slot, n);  // (a rank of 0 on top of the heap at a checkpoint: never written by the replay)
+        d.cp_T[(size_t)i * NCP + lane] = cp_t;
         if (at_start) {
-            d.cp_T[(WA + i) * NCP + lane] = t;
-            d.cp_road[(WA + i) * NCP + lane] = d.cp_road[(size_t)i * NCP + lane];
+            d.cp_T[(WA + i) * NCP + lane] = cp_t;
+            d.cp_road[(WA + i) * NCP + lane] = cp_r;
         }
     }
     if (lane == 0) {
@@ -1079,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
         d.cp_hdr[i] = make_float4(ex, ey, __int_as_float(ncp), 0.f);
         if (at_start) d.cp_hdr[WA + i] = make_float4(ex, ey, __int_as_float(ncp), 0.f);
         d.sel_hdr[(size_t)i * 2] = make_float4(ex, ey, qw, qz);
-        d.sel_hdr[(size_t)i * 2 + 1] = make_float4(__int_as_float(m), __int_as_float(r0), 0.f, 0.f);
+        d.sel_hdr[(size_t)i * 2 + 1] = make_float4(__int_as_float(m), __int_as_float(r0), __int_as_float(1), 0.f);
     }
 }
 

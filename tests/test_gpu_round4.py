@@ -1,0 +1,201 @@
+"""GPU suite, round 4: the rank replay (csrc/map_obs_rank.hip) where the product uses it but no test had it --
+world rebuilds (`set_maps` big -> small -> big, `deleteAgents`: `reset_rank_state` / `ensure_rank_buffers` into live rank
+buffers), the device-driven reset of the episode tracker (the `gate_any` passes of all the rank kernels), and the ends of its
+arrays (last world, last agent slot, a candidate list that fills the buffer exactly, a replay wave with one active lane).
+Everything goes through `madrona_gpudrive` -> ctypes -> the C ABI; reference: src/knn.hpp:103-158, src/mgr.cpp:590-715,
+gpudrive/env/env_puffer.py:250-403."""
+import json
+import math
+
+import numpy as np
+import pytest
+
+from gpudrive_lab_amd import synth
+from tests import parity as P
+from tests import ref_cases as RC
+
+pytestmark = pytest.mark.gpu
+
+ALL_OBJECTS = dict(isStaticAgentControlled=1, initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
+BENCH = dict(observationRadius=50.0, collisionBehaviour=2, rewardType=1, distanceToGoalThreshold=2.0, dynamicsModel=0,
+             roadObservationAlgorithm=0, polylineReductionThreshold=0.0, **ALL_OBJECTS)
+
+
+def _scene(tmp_path, name, n_agents, n_poly, pts, seed):
+    p = tmp_path / (name + ".json")
+    p.write_text(json.dumps(synth.make_scene(seed, n_agents=n_agents, n_polylines=n_poly, pts_per_polyline=pts)))
+    return str(p)
+
+
+def _ranked(gpu):
+    """(agents ranked in the last selection, agents that needed the fallback although their world has K roads or more)"""
+    path = gpu.debug_road_path()
+    big = (RC.as_np(gpu.shape_tensor())[:, 1] >= 200)[:, None]
+    return int((path > 0).sum()), int((((path == -1) | (path <= -10)) & big).sum())
+
+
+# ---- world rebuilds on the rank path ----
+def test_rank_path_through_set_maps_and_delete_agents(oracle_mod, tmp_path, monkeypatch):
+    """`set_maps` big -> small -> big and `deleteAgents` with the rank replay forced on for every world that has K roads:
+    after each rebuild the first selection takes the fallback (no checkpoint survives), the following ones the rank path
+    again -- in lockstep with the oracle all the way (ints exact, observations under teacher forcing)."""
+    monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")
+    big_a = _scene(tmp_path, "big_a", 20, 12, 129, 11)    # 1536 roads
+    big_b = _scene(tmp_path, "big_b", 64, 16, 129, 12)    # 2048 roads, every agent slot live
+    mid = _scene(tmp_path, "mid", 9, 10, 60, 13)          # 590 roads
+    small = _scene(tmp_path, "small", 6, 2, 65, 14)       # 128 roads: below K, never ranked
+    kw = dict(BENCH, observationRadius=60.0)
+    scenes = [big_a, big_b, mid]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    assert gpu.stat(7) == 1
+    P.compare_fresh(gpu, orc)
+    P.lockstep(gpu, orc, 4, 0, seed=1)
+    ranked, fell = _ranked(gpu)
+    assert ranked > 0 and fell == 0, (ranked, fell)
+    seed = 2
+    for new in ([small, mid, small], [big_b, big_a, big_b], [small, small, small], [mid, big_b, big_a]):
+        gpu.set_maps(new)
+        orc.set_maps(new)
+        P.compare_fresh(gpu, orc)
+        P.lockstep(gpu, orc, 4, 0, seed=seed)
+        seed += 1
+        ranked, fell = _ranked(gpu)
+        has_k = any(s is not small for s in new)
+        assert (ranked > 0) == has_k and fell == 0, (new, ranked, fell)
+    # deleteAgents rebuilds two of the three worlds into the live rank buffers
+    ids = np.asarray(orc.agent_id_tensor())
+    victims = {1: [int(ids[1, 0]), int(ids[1, 63]), int(ids[1, 17])], 2: [int(ids[2, 3])]}
+    gpu.deleteAgents(victims)
+    orc.deleteAgents(victims)
+    P.compare_fresh(gpu, orc)
+    P.lockstep(gpu, orc, 5, 0, seed=9)
+    ranked, fell = _ranked(gpu)
+    assert ranked > 0 and fell == 0
+    # a partial reset in between, then on
+    gpu.reset([1])
+    orc.reset([1])
+    P.compare_fresh(gpu, orc)
+    P.lockstep(gpu, orc, 3, 0, seed=10)
+    gpu.close()
+
+
+# ---- the device-driven reset (gate_any passes) on the rank path ----
+def test_episode_tracker_auto_reset_on_the_rank_path(oracle_mod, tmp_path):
+    """`EpisodeTracker(auto_reset)` -- what bench.py's `rl_loop` line runs every step -- on two bench-sized worlds (4096 and
+    2048 roads: rank path by default) through more than two episode ends per world: every step launches the gated reset
+    pass (all six rank kernels return at once unless a world finished), a finished world is reset on the device and its
+    agents go back to the episode's first checkpoints.  Bookkeeping bit-exact against oracle/episode.py, the simulator in
+    lockstep with the oracle."""
+    from gpudrive_lab_amd.episode import EpisodeTracker
+    from oracle.episode import OracleEpisodeTracker
+    kw = dict(BENCH, collisionBehaviour=0, maxNumControlledAgents=4, isStaticAgentControlled=0)
+    scenes = [synth.write_scenes(str(tmp_path), [3])[0], _scene(tmp_path, "half", 40, 16, 129, 21)]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    assert gpu.stat(7) == 1
+    gt = EpisodeTracker(gpu, collision_weight=-0.75, goal_achieved_weight=1.0, off_road_weight=-0.5)
+    ot = OracleEpisodeTracker(orc, collision_weight=-0.75, goal_achieved_weight=1.0, off_road_weight=-0.5)
+    rng = np.random.default_rng(4)
+    bits = lambda x: np.ascontiguousarray(x, np.float32).view(np.uint32)
+    finished = np.zeros(2, np.int64)
+    ranked_steps = 0
+    for k in range(200):
+        act = P.random_actions(rng, orc.W, orc.A, 0)
+        act[..., 0] = np.abs(act[..., 0])
+        P.write_actions(gpu, act)
+        np.copyto(orc.action_tensor(), act)
+        o_rew, o_term, o_trunc, o_mask, o_done = ot.step()
+        g_rew, g_term, g_trunc, g_mask = [t.cpu().numpy() for t in gt.step()]
+        try:
+            assert np.array_equal(bits(g_rew), bits(o_rew)), "rewards"
+            assert np.array_equal(g_term, o_term) and np.array_equal(g_trunc, o_trunc) and np.array_equal(g_mask, o_mask)
+            assert np.array_equal(gt.done_worlds.cpu().numpy(), o_done), "done worlds"
+            finished += o_done != 0
+            P.compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+            P.compare_state(gpu, orc)
+            if o_done.any() or k % 5 == 0:
+                P.inject_and_compare(gpu, orc)
+        except AssertionError as e:
+            raise AssertionError("step %d: %s" % (k + 1, e))
+        ranked_steps += _ranked(gpu)[0] > 0
+    assert (finished >= 2).all(), finished
+    assert ranked_steps > 150, "the rank replay should carry these worlds (%d of 200 steps)" % ranked_steps
+    gpu.close()
+
+
+# ---- the ends of the rank path's arrays ----
+def _spiral_scene(tmp_path, name, n_roads, n_agents=64):
+    """One polyline that winds inwards around a point, every segment closer to it than all the segments before: for an agent
+    parked at that point EVERY road is an insert (src/knn.hpp:138-151), i.e. a candidate, so the candidate count is the road
+    count.  The agent is the LAST of the scene's agents; all the others are parked far outside the map."""
+    cx, cy = 200.0, -100.0
+    pts = []
+    for j in range(n_roads + 1):
+        r = 48.0 - 44.0 * j / n_roads
+        th = 0.11 * j
+        pts.append({"x": cx + r * math.cos(th), "y": cy + r * math.sin(th), "z": 0.0})
+
+    def obj(i, x, y):
+        return {"position": [{"x": x, "y": y, "z": 0.0}] * 91, "width": 2.0, "length": 4.5, "height": 1.6, "heading": [0.3] * 91,
+                "velocity": [{"x": 0.0, "y": 0.0}] * 91, "valid": [True] * 91, "goalPosition": {"x": x + 500.0, "y": y, "z": 0.0},
+                "type": "vehicle", "id": i, "mark_as_expert": False}
+    objects = [obj(i, 3000.0 + 20.0 * i, 2000.0) for i in range(n_agents - 1)] + [obj(n_agents - 1, cx, cy)]
+    sc = {"name": name, "scenario_id": name, "objects": objects,
+          "roads": [{"geometry": pts, "type": "road_edge", "map_element_id": 15, "id": 0}],
+          "tl_states": {}, "metadata": {"sdc_track_index": 0, "objects_of_interest": [], "tracks_to_predict": []}}
+    p = tmp_path / (name + ".json")
+    p.write_text(json.dumps(sc))
+    return str(p)
+
+
+def test_rank_path_at_the_ends_of_its_arrays(oracle_mod, tmp_path, monkeypatch):
+    """The worst case at the end of every rank array: the LAST agent slot of the LAST world is the only ranked agent of the
+    batch's last replay wave (its 63 neighbours are out of reach of every road), its candidate list is the longest the buffer takes
+    (1279 = GD_RANK_CAP - 1: the replay's block prefetch runs into the slack behind the last row of rk_E), and all of its
+    roads are inside the radius.  The world before it has eleven roads too many for the buffer (overflow: fallback, then the
+    bypass streak).  Rows against the oracle at every step, and the device-side bounds audit must stay at zero."""
+    monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")
+    cap = _spiral_scene(tmp_path, "cap", 1279)
+    over = _spiral_scene(tmp_path, "over", 1290)
+    plain = _scene(tmp_path, "plain", 5, 4, 80, 31)   # 316 roads, a handful of agents
+    scenes = [plain, over, cap]
+    kw = dict(BENCH, observationRadius=60.0)
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    assert gpu.stat(7) == 1
+    P.compare_fresh(gpu, orc)
+    zero = np.zeros((3, 64, 10), np.float32)
+    seen_cap = seen_over = 0
+    for k in range(8):
+        P.write_actions(gpu, zero)   # parked: the candidate sets stay what they are
+        np.copyto(orc.action_tensor(), zero)
+        gpu.step()
+        orc.step()
+        P.compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+        P.inject_and_compare(gpu, orc)
+        path = gpu.debug_road_path()
+        seen_cap += path[2, 63] == 1279
+        seen_over += path[1, 63] in (-11, -13)   # overflow, then the group bypasses the rank kernels
+        # the parked agents are out of reach of every road (-3); those that share the overflowing agent's group of 32 are
+        # selected with it by k_map_obs (-1), to the same empty rows
+        assert (path[2, :63] == -3).all() and np.isin(path[1, :63], (-3, -1)).all(), path[1:, :63]
+    assert seen_cap >= 6, "the last agent slot should be ranked with GD_RANK_CAP - 1 candidates (%d of 8 steps)" % seen_cap
+    assert seen_over >= 6, "1290 candidates overflow the buffer (%d of 8 steps)" % seen_over
+    rows = RC.as_np(gpu.agent_roadmap_tensor())
+    assert (rows[2, 63, :, 6] != 0).all() and (rows[1, 63, :, 6] != 0).all(), "200 roads in reach of the spiral's centre"
+    assert gpu.stat(21) == 0, "device-side bounds audit of the rank path: %d indices out of range" % gpu.stat(21)
+    # the same worlds after a rebuild into the live buffers, the spiral now FIRST (agent slot 63 of world 0)
+    new = [cap, plain, over]
+    gpu.set_maps(new)
+    orc.set_maps(new)
+    P.compare_fresh(gpu, orc)
+    for k in range(3):
+        P.write_actions(gpu, zero)
+        np.copyto(orc.action_tensor(), zero)
+        gpu.step()
+        orc.step()
+        P.inject_and_compare(gpu, orc)
+    assert gpu.debug_road_path()[0, 63] == 1279
+    assert gpu.stat(21) == 0
+    gpu.close()

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 # the phase switches exist only in a diagnostic build: tools/build_expt.sh diag -DGD_DIAG (before gpurun: the .so travels)
-export GPUDRIVE_AMD_LIB=$GRAFT_REPO_ROOT/gpudrive_lab_amd/expt_diag.so
+export GPUDRIVE_DEV=1 GPUDRIVE_AMD_LIB=$GRAFT_REPO_ROOT/build/expt/expt_diag.so
 [ -f "$GPUDRIVE_AMD_LIB" ] || { echo "build it first: tools/build_expt.sh diag -DGD_DIAG"; exit 1; }
 for D in ${PHASES:-1 2 3 4 5 0}; do
   OUT=gpurun_out/phase_$D; rm -rf $OUT; mkdir -p $OUT

@@ -5,7 +5,8 @@ import os, sys, time
 os.environ.setdefault("GPUDRIVE_MAX_AGENTS", "64")
 os.environ["GPUDRIVE_RANK_DBG"] = "9"  # switches the counters on
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["GPUDRIVE_AMD_LIB"] = os.path.join(ROOT, "gpudrive_lab_amd", "expt_%s.so" % os.environ.get("EXPT", "diag"))
+os.environ["GPUDRIVE_DEV"] = "1"
+os.environ["GPUDRIVE_AMD_LIB"] = os.path.join(ROOT, "build", "expt", "expt_%s.so" % os.environ.get("EXPT", "diag"))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench

@@ -1,13 +1,13 @@
 #!/bin/bash
-# developer tool: build the library with in-kernel cycle stamps (-DGD_STAMPS, gpudrive_lab_amd/stamps.so, built HERE
+# developer tool: build the library with in-kernel cycle stamps (-DGD_STAMPS, build/expt/stamps.so, built HERE
 # before gpurun) and print where a workgroup of the road kernel spends its cycles.
 #   build:  tools/stamps.sh build      run on the GPU box:  tools/stamps.sh run [workload]
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
-  cd gpudrive_lab_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DGD_STAMPS --offload-arch=gfx950 -shared -o ../stamps.so kernels.hip map_obs.hip bev_lidar.hip pack_obs.hip episode.hip engine.cpp scene.cpp scene_cache.cpp
+  mkdir -p build/expt && cd gpudrive_lab_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DGD_STAMPS --offload-arch=gfx950 -shared -o ../../build/expt/stamps.so kernels.hip map_obs.hip bev_lidar.hip pack_obs.hip episode.hip engine.cpp scene.cpp scene_cache.cpp
   exit $?
 fi
-GPUDRIVE_AMD_LIB=$PWD/gpudrive_lab_amd/stamps.so python3 - "$2" <<'PY'
+GPUDRIVE_DEV=1 GPUDRIVE_AMD_LIB=$PWD/build/expt/stamps.so python3 - "$2" <<'PY'
 import sys, ctypes, numpy as np, torch
 sys.path.insert(0, ".")
 import bench

@@ -2,7 +2,7 @@
 # developer tool: where a workgroup of k_bev spends its cycles (library built with tools/stamps.sh build).
 #   run on the GPU box:  tools/stamps_bev.sh [workload]
 cd "$(dirname "$0")/.."
-GPUDRIVE_AMD_LIB=$PWD/gpudrive_lab_amd/stamps.so python3 - "$1" <<'PY'
+GPUDRIVE_DEV=1 GPUDRIVE_AMD_LIB=$PWD/build/expt/stamps.so python3 - "$1" <<'PY'
 import sys, ctypes, numpy as np, torch
 sys.path.insert(0, ".")
 import bench
