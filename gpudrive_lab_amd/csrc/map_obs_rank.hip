@@ -44,6 +44,7 @@ constexpr int CAP = GD_RANK_CAP;   // candidates per agent
 constexpr int NCP = GD_RANK_NCP;   // checkpoints per agent
 constexpr int SPL = GD_RANK_SPL;   // sorted slots handed to k_knn_finish
 constexpr int KT = GD_RANK_KT;     // key table entries per agent
+constexpr int NMAX = CAP - 8;      // most candidates an agent is ranked with (k_knn_rank: room for the end markers)
 constexpr int TILE = 32;           // candidates between checkpoints
 constexpr int NB = 1280;           // ranking buckets
 constexpr int NLIN = 768;          // of which linear in the key (up to 1.5 x the previous K-th key); the other 512 take
@@ -173,6 +174,11 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
             int state = 1, reason = -1;
             if (R >= K && ddx * ddx + ddy * ddy > far * far) {
                 state = RK_FAR;
+                // every road is beyond the radius: radiusFilter leaves nothing (src/knn.hpp:83-97, 156-157).  No replay, no
+                // checkpoints; the (empty) hand-over to k_map_rows is written here
+                d.sel_hdr[i * 2] = make_float4(ex, ey, d.qw[i], d.qz[i]);
+                d.sel_hdr[i * 2 + 1] = make_float4(__int_as_float(0), __int_as_float(r0), 0.f, 0.f);
+                d.cp_hdr[i] = make_float4(ex, ey, __int_as_float(0), 0.f);
             } else {
                 // the previous selection's checkpoints, or those of the episode's first selection (a reset puts the agent
                 // back where that one was made): whichever was recorded closer to where the agent is now
@@ -391,7 +397,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     int nin = K;
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
-        if (k * 64 >= nch || nin >= CAP) break;  // wave-uniform
+        if (k * 64 >= nch || nin > NMAX) break;  // wave-uniform
         const int c = k * 64 + lane;
         unsigned int wd = in.wd[k];
         if (k == 0) wd = c < K / 32 ? 0u : (c == K / 32 ? wd & ~((1u << (K % 32)) - 1u) : wd);
@@ -402,16 +408,17 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         const int incl = wave_incl_scan(pc);
         int pos = nin + incl - pc;
         nin += __builtin_amdgcn_readlane(incl, 63);
-        if (nin >= CAP) break;  // wave-uniform
+        if (nin > NMAX) break;  // wave-uniform
         while (wd) {
             L.cidx[pos++] = (unsigned short)((c << 5) + __ffs(wd) - 1);
             wd &= wd - 1u;
         }
     }
-    // (CAP itself counts as too many: the sorted key array ends in one +inf entry that reads past a bucket's end run into --
-    // with exactly CAP candidates there was no room for it and the clamp that stood in for it re-read the LAST entry of
-    // the last bucket, which is not necessarily its largest: a candidate of that bucket could count a smaller key twice)
-    if (nin >= CAP) {
+    // (NMAX = CAP - 8: the sorted key array ends in eight +inf entries that reads past a bucket's end run into.  Round 3 took
+    // up to CAP candidates; with exactly CAP there was no room for an end marker and the clamp that stood in for it re-read
+    // the LAST entry of the last bucket, which is not necessarily its largest: a candidate of that bucket could count a
+    // smaller key twice)
+    if (nin > NMAX) {
         if (lane == 0) {
             d.rk_n[i] = 0;
             d.rk_ticket[i] = -3;  // more candidates than the buffer holds
@@ -575,15 +582,18 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     // of LDS round trips with little to issue in between, so it reads generously: the first eight members of every bucket at
     // once (most hold one or two), then four more per trip while any lane's bucket has members left.  Only keys are read;
     // candidates that met their own key more than once (equal keys, rare) get their place among those afterwards.
-    unsigned int e[NG];
+    // (a candidate's rank e replaces its bucket in the upper half of the road-index register: registers decide how many
+    // waves a SIMD holds)
     unsigned int eqmask = 0u;  // bit g: candidate g of this lane shares its key with another candidate
     float *const kt_row = d.rk_kt + (size_t)i * GD_RANK_KT;
     if (lane == 0) kt_row[(nin + 15) >> 4] = kmax_seen;  // behind the last multiple of 16: the largest key
     constexpr int U = 4, M = 8, STEP = 4;
     // A read past the end of the own bucket meets keys of later buckets, which are larger (the bucket function is monotone)
     // and so count neither as smaller nor as equal: no bounds test per member.  Past the last candidate it meets +inf.
-    const int lim = nin;  // < CAP
-    if (lane == 0) L.s.skey[nin] = __builtin_inff();
+    // Past the last candidate: eight entries of +inf, so that the first M members are read at constant offsets from the
+    // bucket's start with no clamp (three vector instructions per member less: k_knn_rank 407 -> 391 us)
+    const int lim = nin;  // <= NMAX
+    if (lane < 8) L.s.skey[nin + lane] = __builtin_inff();
     wave_sync();
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += U) {
@@ -598,8 +608,9 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
 #pragma unroll
         for (int u = 0; u < U; u++) {
             float mk[M];
+            static_assert(M <= 8, "end markers");
 #pragma unroll
-            for (int k = 0; k < M; k++) mk[k] = L.s.skey[min(s0[u] + k, lim)];
+            for (int k = 0; k < M; k++) mk[k] = L.s.skey[s0[u] + k];  // s0 < nin: at most nin + 6
             less[u] = s0[u];
             eq[u] = 0;
             longest = max(longest, s1[u] - s0[u]);
@@ -632,7 +643,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         for (int u = 0; u < U; u++) {
             const bool on = (g0 + u) * 64 + lane < nin;
             eqmask |= ((eq[u] > 1) & on) ? 1u << (g0 + u) : 0u;  // (a candidate meets itself once)
-            e[g0 + u] = (unsigned int)((less[u] + 1) << 5);
+            ci[g0 + u] = (ci[g0 + u] & 0xffff) | ((less[u] + 1) << 21);  // e = (less + 1) << 5 | tie, in bits 16..31
             // the key table for k_knn_finish: this key sits at the sorted slots [less, less + eq); whoever holds slot 16 j
             // writes entry j (candidates with equal keys write the same value)
             const int j = (less[u] + 15) >> 4;
@@ -653,7 +664,16 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             for (int k = 0; k < NG; k++) cg = k == g ? ci[k] : cg;
             int tie = 0;
             if ((eqmask >> g) & 1u) {
-                const int b = cg >> 16, p = g * 64 + lane;
+                // (the candidate's bucket made way for its rank: found again as the bucket whose range of sorted slots holds
+                // `less`, eleven probes of the cursors -- this pass is rare)
+                const int less_g = (int)((unsigned int)cg >> 21) - 1, p = g * 64 + lane;
+                int lo = 0, hi = NB - 1;
+#pragma clang loop unroll(disable)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)cur16[mid] > less_g) hi = mid; else lo = mid + 1;
+                }
+                const int b = lo;
                 const int first = b ? (int)cur16[b - 1] : 0, end = (int)cur16[b];
                 float kg = 0.f;  // the candidate's key, from its own entry of the bucket (the key registers are long gone)
                 for (int m = first; m < end; m++) kg = (int)L.s.spos[m] == p ? L.s.skey[m] : kg;
@@ -661,7 +681,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             }
             too_many_ties |= tie > 31 ? 1 : 0;
 #pragma unroll
-            for (int k = 0; k < NG; k++) e[k] |= k == g ? (unsigned int)(tie & 31) : 0u;
+            for (int k = 0; k < NG; k++) ci[k] |= k == g ? (tie & 31) << 16 : 0;
         }
     }
     wave_sync();  // every read of the sorted arrays is done: their space becomes the slot -> road table
@@ -686,8 +706,9 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     for (int g = 0; g < NG; g++) {
         if (g * 64 < nin) {  // wave-uniform
             if (g * 64 + lane < nin) {
-                stream_store((unsigned short)e[g], E_row + (g * 64u + ulane));
-                const int slot = (int)(e[g] >> 5) - 1 + (int)(e[g] & 31u);
+                const unsigned int e = (unsigned int)ci[g] >> 16;
+                stream_store((unsigned short)e, E_row + (g * 64u + ulane));
+                const int slot = (int)(e >> 5) - 1 + (int)(e & 31u);
                 if (slot < SPL) L.spc[slot] = (unsigned short)(ci[g] & 0xffff);
             }
         }
@@ -708,7 +729,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
 // A wave ranks several agents in turn: tens of thousands of one-agent workgroups cost more in workgroup launches (each is
 // handed its LDS first) than in work.
 template <int A_T>
-__global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // at most 128 registers: four waves per SIMD, like the LDS
+__global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // (measured: three waves per SIMD without spills 437 us, four with seven spilled registers 391)  // at most 128 registers: four waves per SIMD, like the LDS
     if (d.gate_any && *d.any_reset == 0) return;
     __shared__ RankLds L;
     // Which agents a wave takes: workgroup b runs on XCD b % 8 and shares out the list of the agents that k_knn_scan's
@@ -1047,8 +1068,8 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     if (d.gate_any && *d.any_reset == 0) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = blockIdx.x * 4 + wave;
-    if (li >= d.live_count) return;
-    const int i = d.live_list[li];
+    if (li >= d.rk_hist[512]) return;  // (the grid is sized for every live agent on the rank path)
+    const int i = d.rk_order[li];      // the replay order: exactly the agents whose replay has run
     // Everything the wave reads from global memory depends on `i` alone and every address is valid for any agent slot (stale
     // at worst): requested together, before the first branch looks at any of it -- the kernel is a chain of memory round
     // trips with little arithmetic in between (round 3's version asked for flag, count, pose, heap and table one after the
@@ -1070,16 +1091,9 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     const unsigned int cp_e = d.rk_cpe[(size_t)i * NCP + min(lane, NCP - 1)];
     const unsigned short cp_r = d.cp_road[(size_t)i * NCP + min(lane, NCP - 1)];
     if (fell_back != 0) return;  // k_map_obs selects for this group
-    if (packed == RK_FAR) {  // every road is beyond the radius: radiusFilter leaves nothing (src/knn.hpp:83-97, 156-157)
-        if (lane == 0) {
-            d.sel_hdr[(size_t)i * 2] = make_float4(ex, ey, qw, qz);
-            d.sel_hdr[(size_t)i * 2 + 1] = make_float4(__int_as_float(0), __int_as_float(r0), 0.f, 0.f);
-            d.cp_hdr[i] = make_float4(ex, ey, __int_as_float(0), 0.f);  // no checkpoints: nothing was replayed
-        }
-        return;
-    }
+    // (agents out of reach of every road never get here: k_knn_scan wrote their empty hand-over)
     const int n = packed & 0xffff, nle = (packed >> 16) & 0xfff;
-    if (n < K) return;
+    if (packed <= 0 || packed == RK_FAR || n < K) return;  // took a place in the order, then fell back (equal keys)
     // the checkpoints' K-th keys (see below): the table entry is known as soon as the checkpoint's rank is
     const int cp_slot = (int)(cp_e >> 5) - 1 + (int)(cp_e & 31u);
     const int ncp = 1 + (n - K) / TILE;

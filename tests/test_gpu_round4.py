@@ -152,11 +152,11 @@ def _spiral_scene(tmp_path, name, n_roads, n_agents=64):
 def test_rank_path_at_the_ends_of_its_arrays(oracle_mod, tmp_path, monkeypatch):
     """The worst case at the end of every rank array: the LAST agent slot of the LAST world is the only ranked agent of the
     batch's last replay wave (its 63 neighbours are out of reach of every road), its candidate list is the longest the buffer takes
-    (1279 = GD_RANK_CAP - 1: the replay's block prefetch runs into the slack behind the last row of rk_E), and all of its
-    roads are inside the radius.  The world before it has eleven roads too many for the buffer (overflow: fallback, then the
+    (1272 = GD_RANK_CAP - 8, the most k_knn_rank takes: the replay's block prefetch runs into the slack behind the last row of rk_E), and all of its
+    roads are inside the radius.  The world before it has eighteen roads too many for the buffer (overflow: fallback, then the
     bypass streak).  Rows against the oracle at every step, and the device-side bounds audit must stay at zero."""
     monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")
-    cap = _spiral_scene(tmp_path, "cap", 1279)
+    cap = _spiral_scene(tmp_path, "cap", 1272)
     over = _spiral_scene(tmp_path, "over", 1290)
     plain = _scene(tmp_path, "plain", 5, 4, 80, 31)   # 316 roads, a handful of agents
     scenes = [plain, over, cap]
@@ -175,12 +175,12 @@ def test_rank_path_at_the_ends_of_its_arrays(oracle_mod, tmp_path, monkeypatch):
         P.compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
         P.inject_and_compare(gpu, orc)
         path = gpu.debug_road_path()
-        seen_cap += path[2, 63] == 1279
+        seen_cap += path[2, 63] == 1272
         seen_over += path[1, 63] in (-11, -13)   # overflow, then the group bypasses the rank kernels
         # the parked agents are out of reach of every road (-3); those that share the overflowing agent's group of 32 are
         # selected with it by k_map_obs (-1), to the same empty rows
         assert (path[2, :63] == -3).all() and np.isin(path[1, :63], (-3, -1)).all(), path[1:, :63]
-    assert seen_cap >= 6, "the last agent slot should be ranked with GD_RANK_CAP - 1 candidates (%d of 8 steps)" % seen_cap
+    assert seen_cap >= 6, "the last agent slot should be ranked with GD_RANK_CAP - 8 candidates (%d of 8 steps)" % seen_cap
     assert seen_over >= 6, "1290 candidates overflow the buffer (%d of 8 steps)" % seen_over
     rows = RC.as_np(gpu.agent_roadmap_tensor())
     assert (rows[2, 63, :, 6] != 0).all() and (rows[1, 63, :, 6] != 0).all(), "200 roads in reach of the spiral's centre"
@@ -196,6 +196,6 @@ def test_rank_path_at_the_ends_of_its_arrays(oracle_mod, tmp_path, monkeypatch):
         gpu.step()
         orc.step()
         P.inject_and_compare(gpu, orc)
-    assert gpu.debug_road_path()[0, 63] == 1279
+    assert gpu.debug_road_path()[0, 63] == 1272
     assert gpu.stat(21) == 0
     gpu.close()
