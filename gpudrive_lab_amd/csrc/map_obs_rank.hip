@@ -917,21 +917,10 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
         // The ranks arrive eight at a time (16 bytes), two blocks ahead.  An outer loop per block: the request for block b + 2
         // is issued at the top and its registers are not touched for eight rounds (inside one flat loop the compiler copied the
         // freshly requested block into place at once, i.e. waited a memory round trip every eighth round: a quarter of the kernel)
-#pragma clang loop unroll(disable)
-        for (int p0 = K; p0 < nmax; p0 += 8) {
-          uint4 w8 = cur;
-          cur = nxt;
-          nxt = GD_NT_REPLAY_LOAD ? stream_load(blocks + ((p0 - K) >> 3) + 2) : blocks[((p0 - K) >> 3) + 2];  // may run past this agent's candidates: the array ends in slack.  Every lane, idle
-                                              // ones too (they read row 0): a merge with the old value would wait for the data
-#pragma clang loop unroll(disable)
-          for (int p = p0; p < min(p0 + 8, nmax); p++) {
-            const int t = p - K;
-            const unsigned int y = w8.x & 0xffffu;
-            w8.x = (w8.x >> 16) | (w8.y << 16);
-            w8.y = (w8.y >> 16) | (w8.z << 16);
-            w8.z = (w8.z >> 16) | (w8.w << 16);
-            w8.w = w8.w >> 16;
-            if (p < n && lt(y, r[1])) {
+        // One insert: candidate rank y goes through pop_heap / push_heap (called for the lanes whose candidate passes the
+        // reference's test `cmp(current, heap[0])`, src/knn.hpp:138-143)
+        auto insert = [&](const unsigned int y) {
+            {
 #ifdef GD_CLOCKS
                 n_ins++;
 #endif
@@ -1021,8 +1010,28 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
                     last = min(qv[6], y);
                 }
             }
-            if (((t + 1) & (TILE - 1)) == 0 && p < n) cpe[(t + 1) / TILE] = (unsigned short)r[1];
-          }
+        };
+        // A tile of 32 candidates (what lies between two checkpoints) is four blocks of eight, each block's rounds unrolled:
+        // a round takes its rank out of the block's registers with one instruction, and the checkpoint is written once per
+        // tile (round 3 shifted the block by 16 bits and tested for the checkpoint in every round: a dozen instructions of ~130)
+        static_assert(TILE == 32, "four blocks of eight candidates per checkpoint");
+#pragma clang loop unroll(disable)
+        for (int p0 = K; p0 < nmax; p0 += TILE) {
+#pragma clang loop unroll(disable)
+            for (int pb = p0; pb < min(p0 + TILE, nmax); pb += 8) {
+                const uint4 w8 = cur;
+                cur = nxt;
+                // may run past this agent's candidates: the array ends in slack.  Every lane, idle ones too (they read row 0):
+                // a merge with the old value would wait for the data
+                nxt = GD_NT_REPLAY_LOAD ? stream_load(blocks + ((pb - K) >> 3) + 2) : blocks[((pb - K) >> 3) + 2];
+                const unsigned int wd[4] = {w8.x, w8.y, w8.z, w8.w};
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const unsigned int y = (k & 1) ? wd[k >> 1] >> 16 : wd[k >> 1] & 0xffffu;
+                    if (pb + k < n && lt(y, r[1])) insert(y);
+                }
+            }
+            if (p0 + TILE - 1 < n) cpe[(p0 - K) / TILE + 1] = (unsigned short)r[1];  // after candidate (p0 - K) + 32
         }
     };
     if (__ballot(on && has_tie) != 0ull) replay(std::true_type{});
@@ -1068,8 +1077,11 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     if (d.gate_any && *d.any_reset == 0) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = blockIdx.x * 4 + wave;
-    if (li >= d.rk_hist[512]) return;  // (the grid is sized for every live agent on the rank path)
-    const int i = d.rk_order[li];      // the replay order: exactly the agents whose replay has run
+    // the replay order: exactly the agents whose replay has run.  (The grid is sized for every live agent; the entry is
+    // requested together with the count -- behind the count's end the array holds agent slots of earlier selections or zeros,
+    // valid addresses all -- so that the wave's loads below are one round trip behind this one, not two)
+    const int ranked_agents = d.rk_hist[512];
+    const int i = d.rk_order[min(li, d.W * A_T - 1)];
     // Everything the wave reads from global memory depends on `i` alone and every address is valid for any agent slot (stale
     // at worst): requested together, before the first branch looks at any of it -- the kernel is a chain of memory round
     // trips with little arithmetic in between (round 3's version asked for flag, count, pose, heap and table one after the
@@ -1090,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     const uint2 spc4 = stream_load(reinterpret_cast<const uint2 *>(d.rk_spc + (size_t)i * SPL) + lane);
     const unsigned int cp_e = d.rk_cpe[(size_t)i * NCP + min(lane, NCP - 1)];
     const unsigned short cp_r = d.cp_road[(size_t)i * NCP + min(lane, NCP - 1)];
-    if (fell_back != 0) return;  // k_map_obs selects for this group
+    if (li >= ranked_agents || fell_back != 0) return;  // beyond the order / k_map_obs selects for this group
     // (agents out of reach of every road never get here: k_knn_scan wrote their empty hand-over)
     const int n = packed & 0xffff, nle = (packed >> 16) & 0xfff;
     if (packed <= 0 || packed == RK_FAR || n < K) return;  // took a place in the order, then fell back (equal keys)
