@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
         const int cnt = __float_as_int(meta.x);
         const bool permuted = __float_as_int(meta.z) != 0;
         const size_t e = wa * K + min(q, K - 1);
-        const int idx = (int)d.sel_idx[e];
+        const int idx = (int)d.sel_idx[e];  // (plain loads: as streaming loads these two cost the kernel 20 us, 129 against 109)
         const int slot = (int)d.sel_slot[e];
         on[u] = p < RB && a0 + al < agents && cnt >= 0;  // rows of padding agents are written at reset (k_init_padding_rows)
         in[u] = q < cnt;

@@ -95,6 +95,12 @@ __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlan
 #ifndef GD_NT_SCAN_STORE
 #define GD_NT_SCAN_STORE 0
 #endif
+#ifndef GD_NT_WORDS_LOAD
+#define GD_NT_WORDS_LOAD 1
+#endif
+#ifndef GD_NT_FINISH_LOAD
+#define GD_NT_FINISH_LOAD 1
+#endif
 #ifndef GD_NT_REPLAY_LOAD
 #define GD_NT_REPLAY_LOAD 1
 #endif
@@ -348,7 +354,7 @@ __device__ __forceinline__ RankIn rank_fetch(const DevSim &d, const int *list, i
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
         const int c = k * 64 + lane;
-        in.wd[k] = (in.state == 1 && c < nch) ? stream_load(words + c) : 0u;
+        in.wd[k] = (in.state == 1 && c < nch) ? (GD_NT_WORDS_LOAD ? stream_load(words + c) : words[c]) : 0u;
     }
     return in;
 }
@@ -1097,9 +1103,9 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     const unsigned int *hp = d.rk_heap + (size_t)i * GD_RANK_HEAP_DW;
     unsigned int hpair[NP];
 #pragma unroll
-    for (int ps = 0; ps < NP; ps++) hpair[ps] = stream_load(hp + min((ps * 64 + lane + 1) >> 1, GD_RANK_HEAP_DW - 1));
+    for (int ps = 0; ps < NP; ps++) hpair[ps] = GD_NT_FINISH_LOAD ? stream_load(hp + min((ps * 64 + lane + 1) >> 1, GD_RANK_HEAP_DW - 1)) : hp[min((ps * 64 + lane + 1) >> 1, GD_RANK_HEAP_DW - 1)];
     static_assert(SPL == 256, "four slots per lane");
-    const uint2 spc4 = stream_load(reinterpret_cast<const uint2 *>(d.rk_spc + (size_t)i * SPL) + lane);
+    const uint2 spc4 = GD_NT_FINISH_LOAD ? stream_load(reinterpret_cast<const uint2 *>(d.rk_spc + (size_t)i * SPL) + lane) : reinterpret_cast<const uint2 *>(d.rk_spc + (size_t)i * SPL)[lane];
     const unsigned int cp_e = d.rk_cpe[(size_t)i * NCP + min(lane, NCP - 1)];
     const unsigned short cp_r = d.cp_road[(size_t)i * NCP + min(lane, NCP - 1)];
     if (li >= ranked_agents || fell_back != 0) return;  // beyond the order / k_map_obs selects for this group

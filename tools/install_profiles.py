@@ -12,8 +12,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
-TAGS = ("exact_synthetic", "exact_waymo", "set_synthetic", "set_waymo", "lidar", "cfg3", "set_cfg3", "bev", "rl_loop")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAGS = ("exact_synthetic", "exact_waymo", "set_synthetic", "set_waymo", "lidar", "cfg3", "set_cfg3", "bev", "rl_loop",
+        "exact_synthetic_128", "waymo_raw")
 
 
 def stamp():

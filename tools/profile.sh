@@ -15,7 +15,7 @@ i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM"; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$i -- python3 bench.py --steps 4 --warmup 1 --spin-ms 0 --no-cpu-baseline "$@" > $OUT/bench_pmc_$i.json 2>$OUT/pmc_$i.err
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$i -- python3 bench.py --steps 4 --warmup 1 --spin-ms 0 --no-align --no-cpu-baseline "$@" > $OUT/bench_pmc_$i.json 2>$OUT/pmc_$i.err
   i=$((i+1))
 done
 python3 tools/profile_summarize.py $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Collect every profiles/ tag on the GPU box (about 10 minutes):  gpurun --timeout 1200 -- tools/profile_all.sh [tags...]
-TAGS=${@:-exact_synthetic exact_waymo set_synthetic set_waymo lidar cfg3 set_cfg3 bev rl_loop}
+# Collect every profiles/ tag on the GPU box (about 12 minutes):  gpurun --timeout 1200 -- tools/profile_all.sh [tags...]
+TAGS=${@:-exact_synthetic exact_waymo set_synthetic set_waymo lidar cfg3 set_cfg3 bev rl_loop exact_synthetic_128 waymo_raw}
 for t in $TAGS; do
   case $t in
     exact_synthetic) a="--workloads synthetic";;
@@ -12,6 +12,8 @@ for t in $TAGS; do
     set_cfg3) a="--workloads cfg3 --knn-order 1";;
     bev) a="--workloads bev";;
     rl_loop) a="--workloads rl_loop";;
+    exact_synthetic_128) a="--workloads synthetic_128";;
+    waymo_raw) a="--workloads waymo_raw";;
   esac
   timeout -k 10 400 bash tools/profile.sh $t $a > gpurun_out/prof_$t.log 2>&1 && echo "$t done" || echo "$t FAILED"
 done
