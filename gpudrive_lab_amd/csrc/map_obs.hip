@@ -507,30 +507,36 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     const unsigned int per_xcd = gridDim.x >> 3;  // (the grid is a multiple of 8 workgroups)
     const size_t a0 = (size_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * ROWS_AB;
     if (a0 >= agents) return;
-    // the agent's header (pose, count, first road, permuted: written by the selection kernel), the entry's road index and
-    // its row come in one round trip, the road's 32-byte record in a second one
-    bool on[U], in[U];
+    // A thread takes four CONSECUTIVE entries of one agent (K is a multiple of four): the agent's header (pose, count, first
+    // road, permuted: written by the selection kernel) is read once per thread, the four road indices come as one 8-byte
+    // load and their four rows as one 4-byte load -- four loads where a thread per strided row issued sixteen; the roads'
+    // 32-byte records follow in a second round trip.
+    static_assert(U == 4 && K % 4 == 0, "four consecutive entries of one agent per thread");
+    bool in[U];
     int r[U], dst[U];
-    float4 pose[U];
     __shared__ unsigned char s_on[ROWS_AB];
+    const int t4 = threadIdx.x * 4;
+    const bool act = t4 < RB;
+    const int al = min(t4 / K, ROWS_AB - 1);
+    const int qf = act ? t4 - al * K : 0;
+    const size_t wa = min(a0 + al, agents - 1);
+    const float4 pose = d.sel_hdr[wa * 2];
+    const float4 meta = d.sel_hdr[wa * 2 + 1];
+    const int cnt = __float_as_int(meta.x);
+    const bool permuted = __float_as_int(meta.z) != 0;
+    const size_t e = wa * K + qf;  // a multiple of four: both loads are aligned
+    const uint2 idx4 = *reinterpret_cast<const uint2 *>(d.sel_idx + e);
+    const unsigned int slot4 = *reinterpret_cast<const unsigned int *>(d.sel_slot + e);
+    const bool on = act && a0 + al < agents && cnt >= 0;  // rows of padding agents are written at reset (k_init_padding_rows)
+    if (act && qf == 0) s_on[al] = on ? 1 : 0;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const int p = threadIdx.x + u * 256;
-        const int al = min(p / K, ROWS_AB - 1);
-        const int q = p - al * K;
-        const size_t wa = min(a0 + al, agents - 1);
-        pose[u] = d.sel_hdr[wa * 2];
-        const float4 meta = d.sel_hdr[wa * 2 + 1];
-        const int cnt = __float_as_int(meta.x);
-        const bool permuted = __float_as_int(meta.z) != 0;
-        const size_t e = wa * K + min(q, K - 1);
-        const int idx = (int)d.sel_idx[e];  // (plain loads: as streaming loads these two cost the kernel 20 us, 129 against 109)
-        const int slot = (int)d.sel_slot[e];
-        on[u] = p < RB && a0 + al < agents && cnt >= 0;  // rows of padding agents are written at reset (k_init_padding_rows)
+        const int q = qf + u;
+        const int idx = (int)(((u & 2) ? idx4.y : idx4.x) >> ((u & 1) * 16)) & 0xffff;
+        const int slot = (int)(slot4 >> (u * 8)) & 0xff;
         in[u] = q < cnt;
         r[u] = in[u] ? __float_as_int(meta.y) + idx : 0;
         dst[u] = al * K + ((in[u] && permuted) ? min(slot, K - 1) : q);
-        if (p < RB && q == 0) s_on[al] = on[u] ? 1 : 0;
     }
     float4 q0[U], q1[U];
 #pragma unroll
@@ -544,9 +550,9 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     // and not read again by the step, and must not push the road and agent arrays out of L2 / Infinity Cache.
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        if (threadIdx.x + u * 256 < RB)
-            road_row(s_rows + dst[u] * 9, in[u], d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST, pose[u].x, pose[u].y, pose[u].z,
-                     pose[u].w, q0[u], q1[u]);
+        if (act)
+            road_row(s_rows + dst[u] * 9, in[u], d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST, pose.x, pose.y, pose.z, pose.w,
+                     q0[u], q1[u]);
     }
     __syncthreads();
     float *out = d.agent_map + a0 * (size_t)(K * 9);  // a0 * 7200 bytes: 16-byte aligned
