@@ -156,12 +156,19 @@ struct gd_sim {
             d.rk_order = alloc_internal<int32_t>(WA);
             d.rk_list = alloc_internal<int32_t>(8 * WA);
             d.road_bbox = alloc_internal<float4>(W);
+            // the long list: room for a quarter of the agent slots (an agent beyond that takes the fallback)
+            d.rk_nlong = static_cast<int>(std::max<size_t>(WA / 4, 64));
+            d.rk_longlist = alloc_internal<int32_t>(d.rk_nlong);
+            d.rk_longslot = alloc_internal<int32_t>(WA);
+            d.rk_E_long = alloc_internal<uint16_t>(static_cast<size_t>(d.rk_nlong) * GD_RANK_CAP_LONG + 64);  // (+ the replay's prefetch)
+            d.rk_kt_long = alloc_internal<float>(static_cast<size_t>(d.rk_nlong) * GD_RANK_KT_LONG);
         } catch (const HipError &) {
             (void)hipGetLastError();
             for (size_t k = first; k < internal.size(); k++) (void)hipFree(internal[k]);
             internal.resize(first);
             rk_possible = false;
             d.rk_on = 0;
+            d.rk_nlong = 0;
             return false;
         }
         rk_alloc = true;
@@ -623,7 +630,7 @@ struct gd_sim {
             // of 32 to the fallback (measured: 3.80 ms ranked + fallback against 3.39 on keys alone).  Groups that keep
             // overflowing below this size bypass the rank kernels on their own (rk_streak).
             const char *pin_max = std::getenv("GPUDRIVE_RANK_MAX_ROADS");
-            d.rk_max_roads = pin_max ? std::atoi(pin_max) : 6000;
+            d.rk_max_roads = pin_max ? std::atoi(pin_max) : GD_MAX_ROAD_ENTITIES;
             d.rk_on = 0;
             for (int w = 0; w < W; w++) {
                 const int R = road_off[w + 1] - road_off[w];

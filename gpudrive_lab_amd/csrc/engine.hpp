@@ -15,6 +15,9 @@
 #define GD_RANK_CAP 1280
 #define GD_RANK_NCP 40
 #define GD_RANK_HEAP_DW 104
+#define GD_RANK_CAP_LONG 2560   // candidates of an agent that the long-list instantiation of the ranking takes (map_obs_rank.hip)
+#define GD_RANK_KT_LONG 164     // its key-table row (CAP_LONG / 16 entries + the last, padded to 16 bytes)
+#define GD_RH_LONG 537          // rk_hist: agents on the long list in this selection
 #define GD_RANK_NCH 320  // candidate words per agent: 32 roads each, kMaxRoadEntityCount = 10,000
 #define GD_RANK_SPL 256  // sorted slots whose road index k_knn_rank hands on: the K elements the heap ends with have the K smallest
                          // keys, i.e. fewer than K candidates below them and at most 31 equal ones before them: slot < K + 31
@@ -116,6 +119,12 @@ struct DevSim {
     int rk_min_roads;  // worlds with fewer roads are selected by k_map_obs (the rank path's fixed costs do not pay there)
     int rk_dbg;  // -DGD_DIAG builds only: k_knn_rank stops after phase n (timing only; results are wrong)
     uint16_t *rk_E;        // [W][A][CAP] rank of every candidate, candidate (= road) order
+    // agents with more candidates than the standard ranking holds (the long list: k_knn_rank<A, CAP_LONG>), rk_nlong slots
+    int rk_nlong;
+    int32_t *rk_longlist;  // [rk_nlong] agent slot of every entry (count: rk_hist[GD_RH_LONG])
+    int32_t *rk_longslot;  // [W][A] the entry an agent holds (valid while bit 29 of its rk_n is set)
+    uint16_t *rk_E_long;   // [rk_nlong][CAP_LONG] its ranks
+    float *rk_kt_long;     // [rk_nlong][GD_RANK_KT_LONG] its key table
     uint16_t *rk_spc;      // [W][A][GD_RANK_SPL] sorted slot -> road index, the first GD_RANK_SPL slots
     float *rk_kt;          // [W][A][GD_RANK_KT] key at sorted slot 16 j (16 j < n), then the largest key at j = ceil(n / 16)
     uint32_t *rk_heap;     // [W][A][GD_RANK_HEAP_DW] the replayed heap array as rank pairs

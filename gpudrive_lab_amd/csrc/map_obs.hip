@@ -402,7 +402,7 @@ struct Drain {
 // (oldest unread ring word if the current one is used up, its lowest bit) and its (x, y) requested.  `ring` is
 // this agent's column of the ring (slot c at ring[c * AW]), `head` the number of chunks scanned so far.
 // `cpr` / `cpt`: this agent's checkpoint rows (engine.hpp cp_road / cp_T; null when the rank path is off): after every
-// 32nd candidate the K-th key in force is recorded together with the first road it holds for (rounded up to a whole
+// 64th candidate the K-th key in force is recorded together with the first road it holds for (rounded up to a whole
 // 32-road chunk) -- what map_obs_rank.hip bounds the agent's next selection with.
 __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Drain &s, const unsigned int *ring, const float2 *rxy,
                                             int head, float ex, float ey, float iw, float iz, bool owner,
@@ -421,9 +421,13 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
     if (s.has && key < top.tk[1]) heap.replace_top(owner, key, (unsigned int)s.r_cur, top);  // lanes without an insert sit the block out
     if (s.has) {
         s.done++;
-        if (cpr != nullptr && (s.done & 31) == 0 && (s.done >> 5) < GD_RANK_NCP && owner) {
-            cpr[s.done >> 5] = (unsigned short)min(65535, (s.r_cur + 1 + 31) & ~31);
-            cpt[s.done >> 5] = top.tk[1];
+        // (every 64th candidate: the 40 checkpoint slots then cover the longest list the rank path takes, 2560 candidates.
+        // At every 32nd they ended after 1,248; an agent with a longer history -- unreduced Waymo polylines -- came back
+        // from this fallback with nothing to bound its later roads, overflowed the rank path's buffers at once and was
+        // sent here again, every other selection)
+        if (cpr != nullptr && (s.done & 63) == 0 && (s.done >> 6) < GD_RANK_NCP && owner) {
+            cpr[s.done >> 6] = (unsigned short)min(65535, (s.r_cur + 1 + 31) & ~31);
+            cpt[s.done >> 6] = top.tk[1];
         }
     }
     s.nz = refill ? s.nz & ~(1u << slot_new) : s.nz;
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 #endif
             }
             if (owner) heap.store(top);
-            cp_count = min(GD_RANK_NCP, 1 + (dr.done >> 5));
+            cp_count = min(GD_RANK_NCP, 1 + (dr.done >> 6));
         }
         wave_sync();
         STAMP(t_f0);

@@ -44,13 +44,30 @@ constexpr int CAP = GD_RANK_CAP;   // candidates per agent
 constexpr int NCP = GD_RANK_NCP;   // checkpoints per agent
 constexpr int SPL = GD_RANK_SPL;   // sorted slots handed to k_knn_finish
 constexpr int KT = GD_RANK_KT;     // key table entries per agent
-constexpr int NMAX = CAP - 8;      // most candidates an agent is ranked with (k_knn_rank: room for the end markers)
-constexpr int TILE = 32;           // candidates between checkpoints
-constexpr int NB = 1280;           // ranking buckets
-constexpr int NLIN = 768;          // of which linear in the key (up to 1.5 x the previous K-th key); the other 512 take
+constexpr int TILE = 32;           // candidates between checkpoints (standard agents; long lists: 64)
+// Two instantiations of the ranking.  The standard one takes up to CAP - 8 = 1272 candidates in 10 KB of LDS (sixteen waves
+// per CU) and serves nearly every agent; an agent with more (unreduced Waymo polylines: 200 ln(R / 200) inserts and the
+// superset on top, one agent in eight beyond 6,000 roads; fast agents late in an episode) is put on a list and ranked by
+// the LONG instantiation afterwards: 2552 candidates, 20 KB, ranks of 12 + 4 bits instead of 11 + 5, a checkpoint every 64
+// candidates so that their number still fits the 40 slots.  Round 3 sent such an agent's whole group of 32 to the history
+// replay on keys (k_map_obs), at least a millisecond for the launch, and therefore kept worlds above 6,000 roads off the
+// rank path altogether.
+constexpr int CAP_LONG = GD_RANK_CAP_LONG;
+template <int CAP_T>
+struct RankGeo {
+    static constexpr bool LONG = CAP_T > CAP;
+    static constexpr int NG = CAP_T / 64;          // candidates per lane
+    static constexpr int NMAX = CAP_T - 8;         // most candidates an agent is ranked with (room for the end markers)
+    static constexpr int NB = CAP_T;               // ranking buckets
+    static constexpr int NLIN = CAP_T * 3 / 5;     // of which linear in the key (up to 1.5 x the previous K-th key); the others take
+    static constexpr int TSH = LONG ? 6 : 5;       // log2 (candidates between checkpoints)
+    static constexpr int RSH = LONG ? 4 : 5;       // bits of a rank that count the equal keys before it
+    static constexpr int KTN = LONG ? GD_RANK_KT_LONG : GD_RANK_KT;  // floats per key-table row
+};
+constexpr int NB = RankGeo<CAP>::NB;
                                    // the eight octaves above that, 64 each: about one candidate per bucket on either side
-static_assert(K + (NCP - 1) * TILE >= CAP, "a checkpoint slot for every tile of candidates");
-static_assert(CAP % 64 == 0 && NB % 128 == 0 && CAP < 2047, "geometry; less + 1 fits 11 bits");
+static_assert(K + (NCP - 1) * TILE >= CAP && K + (NCP - 1) * 64 >= CAP_LONG, "a checkpoint slot for every tile of candidates");
+static_assert(CAP % 64 == 0 && NB % 128 == 0 && CAP < 2047 && CAP_LONG % 640 == 0 && CAP_LONG < 4095, "geometry; less + 1 fits 11 / 12 bits");
 static_assert(SPL >= K + 31 && SPL <= CAP && KT >= CAP / 16 + 1, "every slot the finish looks up; an entry per 16 slots + the last");
 constexpr int RK_FAR = 1 << 30;    // rk_n: no road of the world can be within the agent's radius
 constexpr int RK_TIES = 1 << 30;   // rk_ticket: the agent took its place in the replay order, then fell back (equal keys)
@@ -135,7 +152,8 @@ __device__ __forceinline__ int audited(const DevSim &d, int idx, int size) {
 }
 
 // key comparison on ranks: key(a) < key(b)  <=>  (a >> 5) < (b >> 5)  <=>  (a | 31) < b.  0 is "below everything".
-__device__ __forceinline__ bool rank_lt(unsigned int a, unsigned int b) { return (a | 31u) < b; }
+// (tm: 31 for a standard agent's ranks, 15 for a long list's: RankGeo::RSH)
+__device__ __forceinline__ bool rank_lt(unsigned int a, unsigned int b, unsigned int tm = 31u) { return (a | tm) < b; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_knn_scan: one lane per agent, one workgroup (4 waves) per 64 agent slots of a world.  Every road of the world is tested
@@ -160,10 +178,19 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
     const int r0 = d.road_off[w];
     const int R = d.road_off[w + 1] - r0;
 
-    __shared__ float2 s_xy[SCAN_TILE];
+    __shared__ __attribute__((aligned(16))) float2 s_xy[SCAN_TILE];
     __shared__ unsigned short s_first[NCP][64];  // checkpoint q of lane l: first road it holds for ...
     __shared__ float s_thr[NCP][64];             // ... and the scan threshold it gives
     __shared__ int s_ncp[64];                    // checkpoints of lane l; 0: the lane takes no part in the scan
+    // (40 KB in all: four workgroups per CU, i.e. every workgroup of a 1024-world launch resident at once -- with 46 KB, three
+    // per CU and a second generation, the kernel took 91 us instead of 61.  What only the set-up before the scan loop needs
+    // therefore lives in the buffers of the loop: the transpose buffer and the road tile)
+    constexpr int TB = 8;
+    __shared__ __attribute__((aligned(16))) unsigned int s_tr[4][TB][65];
+    static_assert(sizeof(float4) * 64 + sizeof(float) * 192 <= sizeof(unsigned int) * 4 * TB * 65 && 4 * 256 * 4 <= sizeof(float2) * SCAN_TILE, "aliases fit");
+    float4 *const s_hdr = reinterpret_cast<float4 *>(&s_tr[0][0][0]);  // where and how many checkpoints lane l's previous selection recorded
+    float *const s_bx = reinterpret_cast<float *>(s_hdr + 64), *const s_by = s_bx + 64, *const s_bm = s_by + 64;  // position and margin of lane l's agent (for the waves that bound it afresh)
+    unsigned int (*const s_hist)[256] = reinterpret_cast<unsigned int (*)[256]>(s_xy);  // per wave: histogram of squared distances of the roads scanned so far
 
     float ex = 0.f, ey = 0.f;
     if (live) { ex = d.px[i]; ey = d.py[i]; }
@@ -171,6 +198,11 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
     int list_base = 0;                 // ... and where they go in rk_list
     if (wave == 0) {
         int ncp = 0;
+        // (every lane's own checkpoint headers first, published: an agent without a usable bound of its own borrows one below)
+        float4 h0 = make_float4(0.f, 0.f, __int_as_float(0), 0.f), h1 = h0;
+        if (live) { h0 = d.cp_hdr[i]; h1 = d.cp_hdr[WA + i]; }
+        s_hdr[lane] = h0;
+        wave_sync();
         if (live) {
             // too far from every road of the world for any to be within the radius: no rows (a finished agent parked
             // at the padding position, src/sim.cpp:333-343)
@@ -188,30 +220,58 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
             } else {
                 // the previous selection's checkpoints, or those of the episode's first selection (a reset puts the agent
                 // back where that one was made): whichever was recorded closer to where the agent is now
-                const float4 h0 = d.cp_hdr[i], h1 = d.cp_hdr[WA + i];
                 const int n0 = __float_as_int(h0.z), n1 = __float_as_int(h1.z);
                 const float m0 = n0 > 0 ? sqrtf((ex - h0.x) * (ex - h0.x) + (ey - h0.y) * (ey - h0.y)) : __builtin_inff();
                 const float m1 = n1 > 0 ? sqrtf((ex - h1.x) * (ex - h1.x) + (ey - h1.y) * (ey - h1.y)) : __builtin_inff();
-                const int set = m1 < m0 ? 1 : 0;
-                const float move = set ? m1 : m0;
-                ncp = (R >= K && R >= d.rk_min_roads && R <= d.rk_max_roads) ? (set ? n1 : n0) : 0;  // small worlds: k_map_obs is
-                                                                                                   // as fast; the largest overflow
-                // a group that needed the fallback three selections in a row (worlds whose agents overflow the candidate
-                // buffer) stops paying for rank kernels whose work is thrown away; it tries again every 64th selection
+                int set = m1 < m0 ? 1 : 0;
+                float move = set ? m1 : m0;
+                int n_cp = set ? n1 : n0;
+                size_t src = i;  // the agent whose checkpoint rows bound this selection
+                // An agent far from where its own checkpoints were recorded (a logged agent back from the padding position,
+                // src/sim.cpp:370-382: none at all, or the episode's first ones from somewhere else) borrows those of the
+                // agent of its world whose previous selection was made nearest to where it is now: the K-th distance over a
+                // prefix of the roads is a function of the position alone, 1-Lipschitz in it, whoever recorded it.  Without
+                // that every road of the world was a candidate for such an agent: beyond the buffers in a world of 10,000
+                // roads (the whole group of 32 to the fallback, a 3 ms step), the longest replay of the launch in smaller ones.
+                if (move > 6.f) {
+                    float best = move;
+                    int donor = -1;
+                    for (int j = 0; j < 64; j++) {
+                        const float4 hj = s_hdr[j];
+                        const float dj = __float_as_int(hj.z) > 0 ? sqrtf((ex - hj.x) * (ex - hj.x) + (ey - hj.y) * (ey - hj.y)) : __builtin_inff();
+                        if (dj < best) { best = dj; donor = j; }
+                    }
+                    if (donor >= 0) {
+                        move = best;
+                        set = 0;
+                        n_cp = __float_as_int(s_hdr[donor].z);
+                        src = (size_t)w * A_T + a0 + donor;
+                    }
+                }
+                const bool eligible = R >= K && R >= d.rk_min_roads && R <= d.rk_max_roads;  // small worlds: k_map_obs is as fast
+                // a group that needed the fallback three selections in a row (agents that overflow even the long list)
+                // stops paying for rank kernels whose work is thrown away; it tries again every 64th selection
                 const int grp = (int)(i / 32);
-                const bool bypass = ncp > 0 && d.rk_streak[grp] >= 3 && ((d.rk_hist[513] + grp) & 63) != 0;
-                if (ncp <= 0 || bypass) {
+                const bool bypass = eligible && d.rk_streak[grp] >= 3 && ((d.rk_hist[513] + grp) & 63) != 0;
+                const float iw = d.qw[i], iz = d.qz[i];
+                const float z2 = iz * iz;
+                const float det = (1.f - 2.f * z2) * (1.f - 2.f * z2) + 4.f * z2 * (iw * iw);
+                const float margin = 1.00001f / fminf(det, 1.f);
+                if (!eligible || bypass) {
                     state = 0;
                     ncp = 0;
-                    reason = bypass ? -5 : -2;  // -2: no usable checkpoints, or a world below rk_min_roads
+                    reason = bypass ? -5 : -2;  // -2: a world below rk_min_roads (or without K roads)
                     d.rk_fallback[i / 32] = 1;
+                } else if (n_cp <= 0 || move > 6.f) {
+                    // No usable bound -- the first selection after the worlds were built, a logged agent that reappears
+                    // anywhere on the map (src/sim.cpp:370-382) with nobody near: the waves of this workgroup bound it afresh
+                    // below (`bound_afresh`).  Round 3 sent such an agent's group to the history replay on keys.
+                    ncp = -1;
+                    s_bx[lane] = ex; s_by[lane] = ey; s_bm[lane] = margin;
                 } else {
-                    const float iw = d.qw[i], iz = d.qz[i];
-                    const float z2 = iz * iz;
-                    const float det = (1.f - 2.f * z2) * (1.f - 2.f * z2) + 4.f * z2 * (iw * iw);
-                    const float margin = 1.00001f / fminf(det, 1.f);
-                    const unsigned short *cr = d.cp_road + ((size_t)set * WA + i) * NCP;
-                    const float *ct = d.cp_T + ((size_t)set * WA + i) * NCP;
+                    ncp = n_cp;
+                    const unsigned short *cr = d.cp_road + ((size_t)set * WA + src) * NCP;
+                    const float *ct = d.cp_T + ((size_t)set * WA + src) * NCP;
                     float t = 1.f;
                     for (int q = 0; q < ncp; q++) {
                         t = ct[q];
@@ -229,6 +289,7 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
             if (state == RK_FAR) ncp = 0;
         }
         s_ncp[lane] = ncp;
+        if (ncp < 0) ncp = 1;  // (bounded afresh below: on the rank path like the others)
         // the agents on the rank path, as a list: k_knn_rank's waves share THEM out, not the live agents (on the Waymo tiles
         // five agents in six are parked out of reach of every road, and a wave that drew three of the others set the pace).
         // One list per XCD (workgroup b runs on XCD b % 8; k_knn_rank's waves take the list of their own XCD, so an agent's
@@ -237,14 +298,76 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
         ranked = __ballot(ncp > 0);
     }
     __syncthreads();
+    // ---- agents without a usable bound: one wave each streams the world's roads once, in scan order, and keeps a histogram of
+    // their squared distances (16 buckets per octave: the exponent and four mantissa bits).  At up to 39 road counts spaced
+    // geometrically (the K-th distance falls like the logarithm of the roads seen) the upper edge of the bucket that holds the
+    // K-th smallest distance so far is a bound of the K-th distance from there on -- a checkpoint like those a previous
+    // selection leaves, at most 4.4 % loose, made without one.  About 6 us per such agent. ----
+    {
+        const unsigned long long needy = __ballot(s_ncp[lane] < 0);
+        if (needy != 0ull) {
+            constexpr int BASE = (127 - 2) << 4;  // bucket 0: below 2^-2 m^2; bucket 255: 2^13.9 m^2 (118 m) and beyond = unbounded
+            unsigned int *hist = s_hist[wave];
+            int turn = 0;
+            for (unsigned long long rest = needy; rest != 0ull; rest &= rest - 1ull, turn++) {
+                if ((turn & 3) != wave) continue;  // wave-uniform
+                const int al = __ffsll((long long)rest) - 1;
+                const float bx = s_bx[al], by = s_by[al], mg = s_bm[al];
+#pragma unroll
+                for (int k = 0; k < 4; k++) hist[k * 64 + lane] = 0u;
+                if (lane == 0) { s_first[0][al] = (unsigned short)((K / 32) * 32); s_thr[0][al] = __builtin_inff(); }
+                const float ratio = exp2f(log2f(fmaxf((float)R / 256.f, 1.f)) / (float)(NCP - 2));
+                float pf = 256.f, tlast = __builtin_inff();
+                int pq = 256, q = 1;
+                float2 nxt = lane < R ? d.road_xy[r0 + lane] : make_float2(0.f, 0.f);
+                for (int rb = 0; rb < R; rb += 64) {
+                    const float2 xy = nxt;
+                    if (rb + 64 + lane < R) nxt = d.road_xy[r0 + rb + 64 + lane];
+                    if (rb + lane < R) {
+                        const float dx = xy.x - bx, dy = xy.y - by;
+                        const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                        atomicAdd(&hist[min(255, max(0, (int)(__float_as_uint(d2) >> 19) - BASE))], 1u);
+                    }
+                    if (rb + 64 == pq && q < NCP && pq < R) {  // wave-uniform: roads [0, pq) are in the histogram
+                        wave_sync();
+                        const uint4 h = reinterpret_cast<const uint4 *>(hist)[lane];  // lane l owns buckets 4 l .. 4 l + 3
+                        const int own = (int)(h.x + h.y + h.z + h.w);
+                        const int incl = wave_incl_scan(own), excl = incl - own;
+                        int jb = 0, before = excl;
+                        if (before + (int)h.x < K) { before += (int)h.x; jb = 1;
+                            if (before + (int)h.y < K) { before += (int)h.y; jb = 2;
+                                if (before + (int)h.z < K) { jb = 3; } } }
+                        const unsigned long long cross = __ballot(excl < K && incl >= K);  // exactly one lane: pq >= 256 > K
+                        const int Lc = __ffsll((long long)cross) - 1;
+                        const int bucket = 4 * Lc + __builtin_amdgcn_readlane(jb, Lc);
+                        const float T = bucket >= 255 ? __builtin_inff() : __uint_as_float((unsigned int)(bucket + 1 + BASE) << 19);
+                        if (lane == 0) {
+                            const float reach = sqrtf(T) * 1.0001f + 1e-3f;
+                            float thr = reach * reach * 1.0001f * mg * 1.001f;  // (the squared distances here are the scan's own form)
+                            if (!(thr >= 0.f)) thr = __builtin_inff();
+                            s_first[q][al] = (unsigned short)min(pq, 65535);
+                            s_thr[q][al] = thr;
+                        }
+                        tlast = T;
+                        q++;
+                        pf *= ratio;
+                        pq = max(pq + 64, ((int)pf + 63) & ~63);
+                    }
+                }
+                if (lane == 0) {
+                    s_ncp[al] = q;
+                    d.rk_tl[(size_t)w * A_T + a0 + al] = tlast < 1e30f ? tlast : 1.f;  // scales the ranking buckets
+                }
+            }
+            __syncthreads();
+        }
+    }
     const int ncp = s_ncp[lane];
     if (__syncthreads_or(ncp > 0 ? 1 : 0) == 0) return;  // no agent of this workgroup is on the rank path (far, fallback, bypass)
     int q = -1;  // checkpoint in force for this lane
     const int nch = (R + 31) >> 5;
     // A wave takes 16 consecutive chunks of the tile, 8 at a time: the agents' words of a batch are handed over agent-major
     // (k_knn_rank reads an agent's words as one row) through an LDS transpose, 32 bytes per agent, wave and batch
-    constexpr int TB = 8;
-    __shared__ unsigned int s_tr[4][TB][65];
     uint32_t *words = d.rk_words + ((size_t)w * A_T + a0) * GD_RANK_NCH;
     for (int tile = 0; tile < R; tile += SCAN_TILE) {
         __syncthreads();
@@ -304,24 +427,25 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
 // 10 KB of LDS per agent, so that sixteen waves fit a CU: the kernel is a chain of LDS and memory round trips, and with two
 // waves per SIMD (20 KB) it waited 46 % of its cycles (profiles/r03: SQ_WAIT_ANY).  A lane keeps its up to 20 candidates
 // (positions lane, lane + 64, ...) in registers through all passes; LDS holds only what lanes exchange.
+template <int CAP_T>
 struct RankLds {
     union {
-        unsigned short cidx[CAP];       // candidate road indices in road order, while the word expansion hands them to their lanes
+        unsigned short cidx[CAP_T];       // candidate road indices in road order, while the word expansion hands them to their lanes
         struct {
-            float skey[CAP];            // the keys in bucket order
-            unsigned short spos[CAP];   // bucket order -> candidate position
+            float skey[CAP_T];            // the keys in bucket order
+            unsigned short spos[CAP_T];   // bucket order -> candidate position
         } s;
-        unsigned short spc[CAP];        // at the end: sorted slot -> road index
+        unsigned short spc[CAP_T];        // at the end: sorted slot -> road index
     };
-    unsigned int cnt2[NB / 2];          // bucket counters, two u16 per word; then cursors: after the scatter the END of each bucket
+    unsigned int cnt2[RankGeo<CAP_T>::NB / 2];  // bucket counters, two u16 per word; then cursors: after the scatter the END of each bucket
 };
-static_assert(sizeof(RankLds) <= 10240, "sixteen waves per CU");
+static_assert(sizeof(RankLds<CAP>) <= 10240 && sizeof(RankLds<CAP_LONG>) <= 20480, "sixteen / eight waves per CU");
 
 // What the ranking of one agent reads from global memory before it can start, fetched while the previous agent of the
 // wave is being ranked (the fetches are a chain of dependent loads, several microseconds end to end).
 constexpr int WPL = GD_RANK_NCH / 64;  // candidate words per lane
 struct RankIn {
-    int i, state, r0, R;
+    int i, state, r0, R, li;  // li: the entry of the list this agent came from (a long list's scratch rows go by it)
     float ex, ey, iw, iz, t_last;
     unsigned int wd[WPL];
 };
@@ -341,6 +465,7 @@ __device__ __forceinline__ T uniform_load(const T *p) {
 template <int A_T>
 __device__ __forceinline__ RankIn rank_fetch(const DevSim &d, const int *list, int li, int count, int lane) {
     RankIn in;
+    in.li = li;
     in.i = li < count ? uniform_load(list + li) : 0;
     in.state = li < count ? uniform_load(d.rk_n + in.i) : 0;  // (k_knn_scan's; this kernel rewrites it once the agent is ranked)
     const int w = in.i / A_T;
@@ -375,9 +500,12 @@ struct PhaseClock {
 struct PhaseClock {};
 #define GD_PHASE(n)
 #endif
-template <int A_T>
-__device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds &L, PhaseClock &clk, int next_entry,
+template <int A_T, int CAP_T>
+__device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, int lane, RankLds<CAP_T> &L, PhaseClock &clk, int next_entry,
                                            int count, const int *list, RankIn &nxt) {
+    using G = RankGeo<CAP_T>;
+    constexpr int NB = G::NB, NLIN = G::NLIN, NMAX = G::NMAX;
+    constexpr unsigned int TM = (1u << G::RSH) - 1u;  // most equal keys before a candidate that its rank can count
     // The next agent's inputs are requested in the middle of this one, behind the last gather of the keys: vector memory
     // operations complete in order, so requested up front they (1.3 KB from HBM) were what every gather then waited for.
     if (__builtin_amdgcn_readfirstlane(in.state) != 1) {  // fallback or too far from every road (k_knn_scan)
@@ -390,12 +518,48 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     auto unif = [](float v) -> float { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
     const int i = uni(in.i), r0 = uni(in.r0), R = uni(in.R);
     const int group = i / 32;  // 32 consecutive agent slots of a world: the fallback unit (a workgroup of k_map_obs)
-    constexpr int NG = CAP / 64;  // candidates per lane
+    constexpr int NG = G::NG;  // candidates per lane
+
+    // ---- how many candidates?  More than this instantiation ranks: on to the long-list instantiation, or to the fallback ----
+    const int nch = (R + 31) >> 5;
+    {
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < WPL; k++) {
+            const int c = k * 64 + lane;
+            unsigned int wd = k * 64 < nch ? in.wd[k] : 0u;
+            if (k == 0) wd = c < K / 32 ? 0u : (c == K / 32 ? wd & ~((1u << (K % 32)) - 1u) : wd);
+            mine += __popc(wd);
+        }
+        const int total = K + wave_sum(mine);
+        // (NMAX = CAP - 8: the sorted key array ends in eight +inf entries that reads past a bucket's end run into.  Round 3
+        // took up to CAP candidates; with exactly CAP there was no room for an end marker and the clamp that stood in for it
+        // re-read the LAST entry of the last bucket, which is not necessarily its largest: a candidate of that bucket could
+        // count a smaller key twice)
+        if (total > NMAX) {
+            if (lane == 0) {
+                bool passed_on = false;
+                if (!G::LONG && total <= RankGeo<CAP_LONG>::NMAX) {
+                    const int slot = atomicAdd(&d.rk_hist[GD_RH_LONG], 1);
+                    if (slot < d.rk_nlong) {  // (rk_n stays 1, the ticket -1: the long-list launch finds the agent as k_knn_scan left it)
+                        d.rk_longlist[slot] = i;
+                        passed_on = true;
+                    }
+                }
+                if (!passed_on) {
+                    d.rk_n[i] = 0;
+                    d.rk_ticket[i] = -3;  // more candidates than the buffers hold
+                    d.rk_fallback[group] = 1;
+                }
+            }
+            nxt = rank_fetch<A_T>(d, list, next_entry, count, lane);
+            return;
+        }
+    }
 
     // ---- candidate words -> road indices in ascending order ----
     // Roads 0..K-1 are candidates regardless (k_knn_scan sets their bits) and their positions are their indices: written
     // directly, not bit by bit (the lanes that own those seven words would loop 32 times while the others wait)
-    const int nch = (R + 31) >> 5;
     static_assert(K == 200 && CAP >= 256, "roads 0..K-1: four stores per lane");
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -403,7 +567,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     int nin = K;
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
-        if (k * 64 >= nch || nin > NMAX) break;  // wave-uniform
+        if (k * 64 >= nch) break;  // wave-uniform
         const int c = k * 64 + lane;
         unsigned int wd = in.wd[k];
         if (k == 0) wd = c < K / 32 ? 0u : (c == K / 32 ? wd & ~((1u << (K % 32)) - 1u) : wd);
@@ -414,24 +578,10 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         const int incl = wave_incl_scan(pc);
         int pos = nin + incl - pc;
         nin += __builtin_amdgcn_readlane(incl, 63);
-        if (nin > NMAX) break;  // wave-uniform
         while (wd) {
             L.cidx[pos++] = (unsigned short)((c << 5) + __ffs(wd) - 1);
             wd &= wd - 1u;
         }
-    }
-    // (NMAX = CAP - 8: the sorted key array ends in eight +inf entries that reads past a bucket's end run into.  Round 3 took
-    // up to CAP candidates; with exactly CAP there was no room for an end marker and the clamp that stood in for it re-read
-    // the LAST entry of the last bucket, which is not necessarily its largest: a candidate of that bucket could count a
-    // smaller key twice)
-    if (nin > NMAX) {
-        if (lane == 0) {
-            d.rk_n[i] = 0;
-            d.rk_ticket[i] = -3;  // more candidates than the buffer holds
-            d.rk_fallback[group] = 1;
-        }
-        nxt = rank_fetch<A_T>(d, list, next_entry, count, lane);
-        return;
     }
     wave_sync();
     // the agent's place in the replay order (k_knn_bins / k_knn_order: most candidates first).  Taken now: the counter's
@@ -447,8 +597,8 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     // where this selection's checkpoints start to apply (their K-th distances are filled in by k_knn_finish): checkpoint 0
     // is the heap of the first K roads (road indices below K are candidates regardless), checkpoint q the heap after
     // candidate K + 32 q - 1, which holds for every road behind that candidate; rounded up to whole 32-road chunks of the scan
-    if (lane <= (nin - K) / TILE) {
-        const int road = (int)L.cidx[K - 1 + TILE * lane];
+    if (lane <= (nin - K) >> G::TSH) {
+        const int road = (int)L.cidx[K - 1 + (lane << G::TSH)];
         d.cp_road[(size_t)i * NCP + lane] = (unsigned short)(lane ? min(65535, (road + 1 + 31) & ~31) : (K / 32) * 32);
     }
     // A lane has 13 candidates on average, 20 at most.  The passes over them go in groups of GQ with one wave-uniform guard
@@ -591,7 +741,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     // (a candidate's rank e replaces its bucket in the upper half of the road-index register: registers decide how many
     // waves a SIMD holds)
     unsigned int eqmask = 0u;  // bit g: candidate g of this lane shares its key with another candidate
-    float *const kt_row = d.rk_kt + (size_t)i * GD_RANK_KT;
+    float *const kt_row = G::LONG ? d.rk_kt_long + (size_t)uni(in.li) * G::KTN : d.rk_kt + (size_t)i * G::KTN;
     if (lane == 0) kt_row[(nin + 15) >> 4] = kmax_seen;  // behind the last multiple of 16: the largest key
     constexpr int U = 4, M = 8, STEP = 4;
     // A read past the end of the own bucket meets keys of later buckets, which are larger (the bucket function is monotone)
@@ -649,7 +799,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         for (int u = 0; u < U; u++) {
             const bool on = (g0 + u) * 64 + lane < nin;
             eqmask |= ((eq[u] > 1) & on) ? 1u << (g0 + u) : 0u;  // (a candidate meets itself once)
-            ci[g0 + u] = (ci[g0 + u] & 0xffff) | ((less[u] + 1) << 21);  // e = (less + 1) << 5 | tie, in bits 16..31
+            ci[g0 + u] = (ci[g0 + u] & 0xffff) | ((less[u] + 1) << (16 + G::RSH));  // e = (less + 1) << RSH | tie, in bits 16..31
             // the key table for k_knn_finish: this key sits at the sorted slots [less, less + eq); whoever holds slot 16 j
             // writes entry j (candidates with equal keys write the same value)
             const int j = (less[u] + 15) >> 4;
@@ -672,7 +822,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             if ((eqmask >> g) & 1u) {
                 // (the candidate's bucket made way for its rank: found again as the bucket whose range of sorted slots holds
                 // `less`, eleven probes of the cursors -- this pass is rare)
-                const int less_g = (int)((unsigned int)cg >> 21) - 1, p = g * 64 + lane;
+                const int less_g = (int)((unsigned int)cg >> (16 + G::RSH)) - 1, p = g * 64 + lane;
                 int lo = 0, hi = NB - 1;
 #pragma clang loop unroll(disable)
                 while (lo < hi) {
@@ -685,9 +835,9 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
                 for (int m = first; m < end; m++) kg = (int)L.s.spos[m] == p ? L.s.skey[m] : kg;
                 for (int m = first; m < end; m++) tie += (L.s.skey[m] == kg ? 1 : 0) & ((int)L.s.spos[m] < p ? 1 : 0);
             }
-            too_many_ties |= tie > 31 ? 1 : 0;
+            too_many_ties |= tie > (int)TM ? 1 : 0;
 #pragma unroll
-            for (int k = 0; k < NG; k++) ci[k] |= k == g ? (tie & 31) << 16 : 0;
+            for (int k = 0; k < NG; k++) ci[k] |= k == g ? (tie & (int)TM) << 16 : 0;
         }
     }
     wave_sync();  // every read of the sorted arrays is done: their space becomes the slot -> road table
@@ -706,7 +856,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     // smallest keys (slot < K + 31 with equal keys), and that is all k_knn_finish looks up by slot -- the checkpoints'
     // K-th keys come from the key table above (round 3 wrote all CAP slots, 2.5 KB per agent, and k_knn_finish fetched the
     // whole row back for 240 scattered 2-byte reads)
-    unsigned short *const E_row = d.rk_E + (size_t)i * CAP;
+    unsigned short *const E_row = G::LONG ? d.rk_E_long + (size_t)uni(in.li) * CAP_LONG : d.rk_E + (size_t)i * CAP;
     const unsigned int ulane = (unsigned int)lane;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
@@ -714,7 +864,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
             if (g * 64 + lane < nin) {
                 const unsigned int e = (unsigned int)ci[g] >> 16;
                 stream_store((unsigned short)e, E_row + (g * 64u + ulane));
-                const int slot = (int)(e >> 5) - 1 + (int)(e & 31u);
+                const int slot = (int)(e >> G::RSH) - 1 + (int)(e & TM);
                 if (slot < SPL) L.spc[slot] = (unsigned short)(ci[g] & 0xffff);
             }
         }
@@ -726,7 +876,8 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         stream_store(v, reinterpret_cast<uint2 *>(d.rk_spc + (size_t)i * SPL) + ulane);
     }
     if (lane == 0) {
-        d.rk_n[i] = nin | (nle << 16) | (has_tie ? 1 << 28 : 0);
+        d.rk_n[i] = nin | (nle << 16) | (has_tie ? 1 << 28 : 0) | (G::LONG ? 1 << 29 : 0);
+        if (G::LONG) d.rk_longslot[i] = uni(in.li);
         d.rk_ticket[i] = ticket;
     }
     GD_PHASE(6);
@@ -734,29 +885,34 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
 
 // A wave ranks several agents in turn: tens of thousands of one-agent workgroups cost more in workgroup launches (each is
 // handed its LDS first) than in work.
-template <int A_T>
-__global__ __launch_bounds__(64, 4) void k_knn_rank(DevSim d) {  // (measured: three waves per SIMD without spills 437 us, four with seven spilled registers 391)  // at most 128 registers: four waves per SIMD, like the LDS
+template <int A_T, int CAP_T>
+__global__ __launch_bounds__(64, CAP_T > CAP ? 2 : 4) void k_knn_rank(DevSim d) {
+    // (standard: at most 128 registers, four waves per SIMD like the LDS.  Measured: three waves per SIMD without spills
+    // 437 us, four with seven spilled registers 391.  Long lists: 20 KB of LDS, two waves per SIMD, twice the registers)
     if (d.gate_any && *d.any_reset == 0) return;
-    __shared__ RankLds L;
-    // Which agents a wave takes: workgroup b runs on XCD b % 8 and shares out the list of the agents that k_knn_scan's
-    // workgroups on that XCD put on the rank path (rk_list), one entry per wave and turn.  The road points an agent gathers
-    // (32 KB per world on the bench scene) are then in that XCD's L2 already, and the waves resident at a time work on a few
-    // dozen worlds instead of all of them (in agent-major order every generation of waves touched every world: 32 MB against
-    // 4 MB of L2 per XCD; HBM bytes of the road observation 2.16 -> 1.36 GB per step).
-    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7;  // (the grid is a multiple of 8 workgroups)
-    const int count = uniform_load(d.rk_hist + 528 + xcd);
-    const int *list = d.rk_list + (size_t)xcd * d.W * A_T;
-    int t = blockIdx.x >> 3;
+    __shared__ RankLds<CAP_T> L;
+    // Which agents a wave takes.  Standard: workgroup b runs on XCD b % 8 and shares out the list of the agents that
+    // k_knn_scan's workgroups on that XCD put on the rank path (rk_list), one entry per wave and turn.  The road points an
+    // agent gathers (32 KB per world on the bench scene) are then in that XCD's L2 already, and the waves resident at a time
+    // work on a few dozen worlds instead of all of them (in agent-major order every generation of waves touched every world:
+    // 32 MB against 4 MB of L2 per XCD; HBM bytes of the road observation 2.16 -> 1.36 GB per step).  Long lists: the one
+    // list that the standard launch made of the agents it could not hold.
+    constexpr bool LONG = RankGeo<CAP_T>::LONG;
+    const int stride = LONG ? (int)gridDim.x : (int)(gridDim.x >> 3);  // (the standard grid is a multiple of 8 workgroups)
+    const int xcd = blockIdx.x & 7;
+    const int count = LONG ? min(uniform_load(d.rk_hist + GD_RH_LONG), d.rk_nlong) : uniform_load(d.rk_hist + 528 + xcd);
+    const int *list = LONG ? d.rk_longlist : d.rk_list + (size_t)xcd * d.W * A_T;
+    int t = LONG ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
     RankIn cur = rank_fetch<A_T>(d, list, t, count, threadIdx.x);
     PhaseClock clk;
 #ifdef GD_CLOCKS
     for (int k = 0; k < 8; k++) clk.sum[k] = 0u;
     clk.prev = (unsigned int)__builtin_amdgcn_s_memtime();
 #endif
-    for (; t < count; t += per_xcd) {
+    for (; t < count; t += stride) {
         RankIn nxt;
         GD_PHASE(0);  // between agents: the buffers change hands
-        rank_agent<A_T>(d, cur, threadIdx.x, L, clk, t + per_xcd, count, list, nxt);
+        rank_agent<A_T, CAP_T>(d, cur, threadIdx.x, L, clk, t + stride, count, list, nxt);
         wave_sync();  // the LDS buffers change hands
         cur = nxt;
     }
@@ -809,6 +965,7 @@ __global__ __launch_bounds__(256) void k_knn_bins(DevSim d) {
         d.rk_hist[512] = before + incl;  // agents on the rank path
         d.rk_hist[513]++;                // selections so far (k_knn_scan staggers the retries of bypassing groups with it)
         for (int x = 0; x < 8; x++) d.rk_hist[528 + x] = 0;  // the next selection's lists of ranked agents start empty
+        d.rk_hist[GD_RH_LONG] = 0;
     }
 }
 
@@ -829,17 +986,20 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
     constexpr int NPAIR = 128;  // pairs 0..K/2 hold the heap; K/2 + 1 .. 127 stay 0: the "children" of slots beyond the heap
     __shared__ unsigned int s_pair[NPAIR * AWR];
     const RankHeap H{s_pair + (lane % AWR)};
-    int i = 0, n = 0, has_tie = 0;
+    int i = 0, n = 0, has_tie = 0, is_long = 0;
     if (lane < AWR && li < d.rk_hist[512]) {
         i = d.rk_order[li];
         const int packed = d.rk_n[i];
         n = packed & 0xffff;
         has_tie = (packed >> 28) & 1;
+        is_long = (packed >> 29) & 1;  // ranked by the long-list instantiation: its own rows, tile and rank format
         if (d.rk_fallback[i / 32] != 0) n = 0;  // the whole group is selected by k_map_obs
     }
     const bool on = n >= K;  // (with fewer than 64 agents per wave: never true for the upper lanes, which share LDS columns with the lower ones)
     if (__ballot(on) == 0ull) return;
-    const unsigned short *E = d.rk_E + (size_t)i * CAP;
+    const unsigned short *E = (on && is_long) ? d.rk_E_long + (size_t)d.rk_longslot[i] * CAP_LONG : d.rk_E + (size_t)i * CAP;
+    const unsigned int tm = is_long ? 15u : 31u;  // equal-key field of this agent's ranks (RankGeo::RSH)
+    const int tsh = is_long ? 6 : 5;             // log2 (candidates between its checkpoints)
 
     // ---- the first K candidates are roads 0..K-1 in order (src/knn.hpp:112-120) ----
     {
@@ -870,7 +1030,7 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
             while (2 * h + 1 <= K) {  // both children exist: take the larger one (the right one unless it is smaller)
                 const unsigned int p2 = H.pair(h);
                 const unsigned int kl = p2 & 0xffffu, kr = p2 >> 16;
-                const bool right = !rank_lt(kr, kl);
+                const bool right = !rank_lt(kr, kl, tm);
                 H.set(h, right ? kr : kl);
                 h = 2 * h + (right ? 1 : 0);
             }
@@ -880,7 +1040,7 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
             }
             while (h > g) {  // __push_heap towards the sift's own top
                 const unsigned int pv = H.get(h >> 1);
-                if (!rank_lt(pv, x)) break;
+                if (!rank_lt(pv, x, tm)) break;
                 H.set(h, pv);
                 h >>= 1;
             }
@@ -912,7 +1072,7 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
 #endif
     auto replay = [&](auto ties_tag) {
         constexpr bool TIES = decltype(ties_tag)::value;
-        auto lt = [](unsigned int a, unsigned int b) -> bool { return TIES ? rank_lt(a, b) : a < b; };
+        auto lt = [&](unsigned int a, unsigned int b) -> bool { return TIES ? rank_lt(a, b, tm) : a < b; };
         auto larger = [&](unsigned int kl, unsigned int kr, bool &right) -> unsigned int {
             right = !lt(kr, kl);  // the right child unless it is smaller (src/binary_heap.hpp __adjust_heap)
             return TIES ? (right ? kr : kl) : max(kl, kr);
@@ -1037,7 +1197,9 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
                     if (pb + k < n && lt(y, r[1])) insert(y);
                 }
             }
-            if (p0 + TILE - 1 < n) cpe[(p0 - K) / TILE + 1] = (unsigned short)r[1];  // after candidate (p0 - K) + 32
+            // after candidate (p0 - K) + 32: a checkpoint of every standard agent, of a long list at every second tile
+            const int after = p0 - K + TILE;
+            if (p0 + TILE - 1 < n && (after & ((1 << tsh) - 1)) == 0) cpe[after >> tsh] = (unsigned short)r[1];
         }
     };
     if (__ballot(on && has_tie) != 0ull) replay(std::true_type{});
@@ -1100,6 +1262,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     const float ex = d.px[i], ey = d.py[i];
     const float qw = d.qw[i], qz = d.qz[i];
     const uint32_t steps_left = d.steps[i];
+    const int long_slot = d.rk_longslot[i];  // (meaningful only for an agent of the long-list instantiation: bit 29 of rk_n)
     const unsigned int *hp = d.rk_heap + (size_t)i * GD_RANK_HEAP_DW;
     unsigned int hpair[NP];
 #pragma unroll
@@ -1113,10 +1276,14 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     const int n = packed & 0xffff, nle = (packed >> 16) & 0xfff;
     if (packed <= 0 || packed == RK_FAR || n < K) return;  // took a place in the order, then fell back (equal keys)
     // the checkpoints' K-th keys (see below): the table entry is known as soon as the checkpoint's rank is
-    const int cp_slot = (int)(cp_e >> 5) - 1 + (int)(cp_e & 31u);
-    const int ncp = 1 + (n - K) / TILE;
+    const bool is_long = ((packed >> 29) & 1) != 0;
+    const int rsh = is_long ? 4 : 5, tsh = is_long ? 6 : 5;  // rank format and checkpoint spacing (RankGeo)
+    const unsigned int tm = (1u << rsh) - 1u;
+    const int cp_slot = (int)(cp_e >> rsh) - 1 + (int)(cp_e & tm);
+    const int ncp = 1 + ((n - K) >> tsh);
+    const float *kt_row = is_long ? d.rk_kt_long + (size_t)long_slot * GD_RANK_KT_LONG : d.rk_kt + (size_t)i * KT;
     float cp_t = 0.f;
-    if (lane < ncp) cp_t = d.rk_kt[(size_t)i * KT + min(max((cp_slot + 15) >> 4, 0), (n + 15) >> 4)];
+    if (lane < ncp) cp_t = kt_row[min(max((cp_slot + 15) >> 4, 0), (n + 15) >> 4)];
     __shared__ unsigned short s_spc[4][SPL];
     __shared__ unsigned short s_don[4][K];
     __shared__ unsigned int s_bm[4][GD_RANK_NCH];      // one bit per road of the world: selected
@@ -1146,10 +1313,10 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
         if (t < K) {
             const unsigned int p2 = hpair[ps];
             const unsigned int e = (g & 1) ? p2 >> 16 : p2 & 0xffffu;
-            const int less = (int)(e >> 5) - 1;
+            const int less = (int)(e >> rsh) - 1;
             // (a rank of 0 -- an element the replay never wrote -- would ask for slot -1; an element of the final heap has
             // fewer than K keys below it and at most 31 equal ones before it)
-            road[ps] = s_spc[wave][audited(d, less + (int)(e & 31u), min(n, SPL))];
+            road[ps] = s_spc[wave][audited(d, less + (int)(e & tm), min(n, SPL))];
             inr[ps] = less < nle;
         }
         fl[ps] = __ballot(inr[ps]);
@@ -1246,13 +1413,18 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
 
 void launch_map_obs_rank(const DevSim &d, hipStream_t st) {
     if (d.live_count == 0) return;
+    // the long-list ranking: a few hundred persistent waves over however many agents the standard launch passed on (none:
+    // every wave reads the empty count and leaves)
+    const dim3 glong(std::min(std::max(d.rk_nlong, 1), 256));
     const dim3 gr(std::min((d.live_count + 7) / 8 * 8, 256 * 8 * 4)), g4((d.live_count + 3) / 4), gw(d.W * (d.A / 64));  // rank: 8192 persistent waves, 16 per CU resident (LDS)
     if (d.A == 64) {
         hipLaunchKernelGGL((k_knn_scan<64>), gw, dim3(256), 0, st, d);
-        hipLaunchKernelGGL((k_knn_rank<64>), gr, dim3(64), 0, st, d);
+        hipLaunchKernelGGL((k_knn_rank<64, CAP>), gr, dim3(64), 0, st, d);
+        if (d.rk_nlong > 0) hipLaunchKernelGGL((k_knn_rank<64, CAP_LONG>), glong, dim3(64), 0, st, d);
     } else {
         hipLaunchKernelGGL((k_knn_scan<128>), gw, dim3(256), 0, st, d);
-        hipLaunchKernelGGL((k_knn_rank<128>), gr, dim3(64), 0, st, d);
+        hipLaunchKernelGGL((k_knn_rank<128, CAP>), gr, dim3(64), 0, st, d);
+        if (d.rk_nlong > 0) hipLaunchKernelGGL((k_knn_rank<128, CAP_LONG>), glong, dim3(64), 0, st, d);
     }
     hipLaunchKernelGGL(k_knn_bins, dim3(1), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_knn_order, dim3((d.live_count + 255) / 256), dim3(256), 0, st, d);

@@ -142,7 +142,9 @@ def _spiral_scene(tmp_path, name, n_roads, n_agents=64):
                 "type": "vehicle", "id": i, "mark_as_expert": False}
     objects = [obj(i, 3000.0 + 20.0 * i, 2000.0) for i in range(n_agents - 1)] + [obj(n_agents - 1, cx, cy)]
     sc = {"name": name, "scenario_id": name, "objects": objects,
-          "roads": [{"geometry": pts, "type": "road_edge", "map_element_id": 15, "id": 0}],
+          # (the scene format caps a polyline at 1746 points: longer spirals continue in a second and third polyline)
+          "roads": [{"geometry": pts[lo:lo + 1501], "type": "road_edge", "map_element_id": 15, "id": lo // 1500}
+                    for lo in range(0, n_roads, 1500)],
           "tl_states": {}, "metadata": {"sdc_track_index": 0, "objects_of_interest": [], "tracks_to_predict": []}}
     p = tmp_path / (name + ".json")
     p.write_text(json.dumps(sc))
@@ -151,22 +153,25 @@ def _spiral_scene(tmp_path, name, n_roads, n_agents=64):
 
 def test_rank_path_at_the_ends_of_its_arrays(oracle_mod, tmp_path, monkeypatch):
     """The worst case at the end of every rank array: the LAST agent slot of the LAST world is the only ranked agent of the
-    batch's last replay wave (its 63 neighbours are out of reach of every road), its candidate list is the longest the buffer takes
-    (1272 = GD_RANK_CAP - 8, the most k_knn_rank takes: the replay's block prefetch runs into the slack behind the last row of rk_E), and all of its
-    roads are inside the radius.  The world before it has eighteen roads too many for the buffer (overflow: fallback, then the
-    bypass streak).  Rows against the oracle at every step, and the device-side bounds audit must stay at zero."""
+    batch's last replay wave (its 63 neighbours are out of reach of every road), its candidate list is the longest the
+    standard ranking takes (1272 = GD_RANK_CAP - 8: the replay's block prefetch runs into the slack behind the last row of
+    rk_E), and all of its roads are inside the radius.  The world before it has eighteen roads too many for that (the
+    long-list instantiation ranks it: 1290 candidates, entry 0 of the long rows), the one before that more than even the
+    long list holds (4000 roads: overflow, fallback, then the bypass streak).  Rows against the oracle at every step, and the
+    device-side bounds audit must stay at zero."""
     monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")
     cap = _spiral_scene(tmp_path, "cap", 1272)
     over = _spiral_scene(tmp_path, "over", 1290)
+    huge = _spiral_scene(tmp_path, "huge", 4000)
     plain = _scene(tmp_path, "plain", 5, 4, 80, 31)   # 316 roads, a handful of agents
-    scenes = [plain, over, cap]
+    scenes = [plain, huge, over, cap]
     kw = dict(BENCH, observationRadius=60.0)
     gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
     orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
     assert gpu.stat(7) == 1
     P.compare_fresh(gpu, orc)
-    zero = np.zeros((3, 64, 10), np.float32)
-    seen_cap = seen_over = 0
+    zero = np.zeros((4, 64, 10), np.float32)
+    seen_cap = seen_over = seen_huge = 0
     for k in range(8):
         P.write_actions(gpu, zero)   # parked: the candidate sets stay what they are
         np.copyto(orc.action_tensor(), zero)
@@ -175,18 +180,21 @@ def test_rank_path_at_the_ends_of_its_arrays(oracle_mod, tmp_path, monkeypatch):
         P.compare_ints(gpu, orc, ["done_tensor", "info_tensor", "steps_remaining_tensor"])
         P.inject_and_compare(gpu, orc)
         path = gpu.debug_road_path()
-        seen_cap += path[2, 63] == 1272
-        seen_over += path[1, 63] in (-11, -13)   # overflow, then the group bypasses the rank kernels
+        seen_cap += path[3, 63] == 1272
+        seen_over += path[2, 63] == 1290            # ranked by the long-list instantiation
+        seen_huge += path[1, 63] in (-11, -13)      # overflow, then the group bypasses the rank kernels
         # the parked agents are out of reach of every road (-3); those that share the overflowing agent's group of 32 are
         # selected with it by k_map_obs (-1), to the same empty rows
-        assert (path[2, :63] == -3).all() and np.isin(path[1, :63], (-3, -1)).all(), path[1:, :63]
+        assert (path[3, :63] == -3).all() and (path[2, :63] == -3).all() and np.isin(path[1, :63], (-3, -1)).all(), path[1:, :63]
     assert seen_cap >= 6, "the last agent slot should be ranked with GD_RANK_CAP - 8 candidates (%d of 8 steps)" % seen_cap
-    assert seen_over >= 6, "1290 candidates overflow the buffer (%d of 8 steps)" % seen_over
+    assert seen_over >= 6, "1290 candidates go to the long list (%d of 8 steps)" % seen_over
+    assert seen_huge >= 6, "the 4000-road spiral overflows every buffer (%d of 8 steps)" % seen_huge
     rows = RC.as_np(gpu.agent_roadmap_tensor())
-    assert (rows[2, 63, :, 6] != 0).all() and (rows[1, 63, :, 6] != 0).all(), "200 roads in reach of the spiral's centre"
+    for w in (1, 2, 3):
+        assert (rows[w, 63, :, 6] != 0).all(), "200 roads in reach of the spiral's centre"
     assert gpu.stat(21) == 0, "device-side bounds audit of the rank path: %d indices out of range" % gpu.stat(21)
-    # the same worlds after a rebuild into the live buffers, the spiral now FIRST (agent slot 63 of world 0)
-    new = [cap, plain, over]
+    # the same worlds after a rebuild into the live buffers, the spirals now FIRST (agent slot 63 of worlds 0 and 1)
+    new = [cap, over, plain, huge]
     gpu.set_maps(new)
     orc.set_maps(new)
     P.compare_fresh(gpu, orc)
@@ -196,6 +204,7 @@ def test_rank_path_at_the_ends_of_its_arrays(oracle_mod, tmp_path, monkeypatch):
         gpu.step()
         orc.step()
         P.inject_and_compare(gpu, orc)
-    assert gpu.debug_road_path()[0, 63] == 1272
+    path = gpu.debug_road_path()
+    assert path[0, 63] == 1272 and path[1, 63] == 1290
     assert gpu.stat(21) == 0
     gpu.close()
