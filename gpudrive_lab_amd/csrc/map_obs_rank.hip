@@ -1411,11 +1411,14 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
 
 }  // namespace
 
+#ifndef GD_RANK_LONG_GRID
+#define GD_RANK_LONG_GRID 2048  // (an empty launch costs 5 us whatever its size; 256 waves ranked the long lists of the unreduced Waymo tiles in 614 us, 2048 in 157)
+#endif
 void launch_map_obs_rank(const DevSim &d, hipStream_t st) {
     if (d.live_count == 0) return;
-    // the long-list ranking: a few hundred persistent waves over however many agents the standard launch passed on (none:
+    // the long-list ranking: persistent waves (eight per CU fit) over however many agents the standard launch passed on (none:
     // every wave reads the empty count and leaves)
-    const dim3 glong(std::min(std::max(d.rk_nlong, 1), 256));
+    const dim3 glong(std::min(std::max(d.rk_nlong, 1), GD_RANK_LONG_GRID));
     const dim3 gr(std::min((d.live_count + 7) / 8 * 8, 256 * 8 * 4)), g4((d.live_count + 3) / 4), gw(d.W * (d.A / 64));  // rank: 8192 persistent waves, 16 per CU resident (LDS)
     if (d.A == 64) {
         hipLaunchKernelGGL((k_knn_scan<64>), gw, dim3(256), 0, st, d);

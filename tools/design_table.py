@@ -1,53 +1,55 @@
 #!/usr/bin/env python3
-"""developer tool: rewrite the numeric cells of DESIGN.md §6's results table from profiles/r03_bench_driver_command.json (first
-figure of each cell) and profiles/r03_bench_default.json (in brackets); the other columns and the rest of the file stay."""
+"""developer tool: DESIGN.md section 6's results table (between the `<!-- results table -->` markers) from the committed bench
+lines: profiles/r04_bench_driver_command.json (first figure of each cell), profiles/r04_bench_default.json (in brackets) and
+profiles/r03_bench_driver_command.json (the round-3 column)."""
 import json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(f):
-    d = json.loads(open(f).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", f)).read().strip().splitlines()[-1])
     out = {}
-    for r in [d] + d["other_workloads"]:
-        out[r.get("workload", "synthetic")] = dict(ms=r["ms_per_step"], ev=r["ms_per_step_events"], ks=r["kernels_sum_us"] / 1e3,
-                                                   rate=r.get("agent_steps_per_s", d["value"]) / 1e6,
-                                                   road=r["kernels"]["k_map_obs+k_map_rows"]["avg_us"] / 1e3,
-                                                   frac=100 * r["roofline"]["frac"], k=r["kernels"])
-    return out
+    for r in [dict(d, workload="synthetic", agent_steps_per_s=d["value"])] + d["other_workloads"]:
+        out[r["workload"]] = r
+    return out, d
 
 
-A = load(os.path.join(ROOT, "profiles", "r03_bench_driver_command.json"))
-B = load(os.path.join(ROOT, "profiles", "r03_bench_default.json"))
-ROWS = {"synthetic exact-64, R = 4096 (primary)": "synthetic", "Waymo tiles (35,489 live agents)": "waymo",
-        "Waymo tiles, 4096 worlds, AgentStop + goal reward (config 3)": "cfg3", "Waymo tiles + 360° LiDAR (config 5)": "lidar",
-        "Waymo tiles + BEV rasters": "bev", "synthetic, learner-side loop (`rl_loop`)": "rl_loop"}
-SET = {"synthetic": "synthetic_set", "Waymo tiles": "waymo_set", "config 3": "cfg3_set"}
-path = os.path.join(ROOT, "DESIGN.md")
-lines = open(path).read().split("\n")
-for n, line in enumerate(lines):
-    if not line.startswith("| "):
-        continue
-    cells = line.split(" | ")
-    if len(cells) < 9:
-        continue
-    name = cells[0][2:]
-    key = ROWS.get(name) if "reference order" in cells[1] else SET.get(name) if "set order" in cells[1] else None
-    if key is None:
-        continue
-    a, b = A[key], B[key]
-    nd = 3 if key == "waymo_set" else 2
-    fmt = lambda x, k=nd: ("%%.%df" % k) % x
-    cells[2] = ("**%s** (%s)" if key == "synthetic" else "%s (%s)") % (fmt(a["ms"]), fmt(b["ms"]))
-    cells[3] = "%s (%s)" % (fmt(a["ev"]), fmt(b["ev"]))
-    cells[4] = fmt(a["ks"]) + (" + `k_pack_obs`, `k_episode_step`" if key == "rl_loop" else "")
-    cells[5] = ("**%.1f M** (%.1f M)" if key == "synthetic" else "%.0f M (%.0f M)" if a["rate"] >= 100 else "%.1f M (%.1f M)") % (a["rate"], b["rate"])
-    road = "%s ms" % fmt(a["road"], 3 if a["road"] < 0.1 else 2)
+A, lineA = load("r04_bench_driver_command.json")
+B, _ = load("r04_bench_default.json")
+C, _ = load("r03_bench_driver_command.json")
+ROWS = [("synthetic exact-64, R = 4096 (primary)", "synthetic", "reference order"),
+        ("Waymo tiles (35,489 live agents, 6.5 K with roads in reach)", "waymo", "reference order"),
+        ("Waymo tiles, 4096 worlds, AgentStop + goal reward (config 3)", "cfg3", "reference order"),
+        ("Waymo tiles + 360° LiDAR (config 5)", "lidar", "reference order"),
+        ("Waymo tiles + BEV rasters", "bev", "reference order"),
+        ("synthetic, learner-side loop (`rl_loop`)", "rl_loop", "reference order"),
+        ("synthetic, 128 agent slots (the fork's `kMaxAgentCount`), all live", "synthetic_128", "reference order"),
+        ("Waymo tiles, unreduced polylines (5,191–10,000 roads per world)", "waymo_raw", "reference order"),
+        ("synthetic", "synthetic_set", "set order"), ("Waymo tiles", "waymo_set", "set order"), ("config 3", "cfg3_set", "set order")]
+out = ["| workload | mode | ms/step | events | Σ kernels | live agent-steps/s | road observation | roofline frac | round 3 |", "|---|---|---|---|---|---|---|---|---|"]
+for name, key, mode in ROWS:
+    a, b, c = A[key], B[key], C.get(key)
+    nd = 3 if a["ms_per_step"] < 0.2 else 2
+    f = lambda x: ("%%.%df" % nd) % x
+    road = a["kernels"]["k_map_obs+k_map_rows"]["avg_us"] / 1e3
+    extra = ""
     if key == "lidar":
-        road += " + `k_lidar` %.2f" % (a["k"]["k_lidar"]["avg_us"] / 1e3)
+        extra = " + `k_lidar` %.2f" % (a["kernels"]["k_lidar"]["avg_us"] / 1e3)
     if key == "bev":
-        road += " + `k_bev` %.2f" % (a["k"]["k_bev"]["avg_us"] / 1e3)
-    cells[6] = road
-    cells[7] = "%.1f %%" % a["frac"]
-    lines[n] = " | ".join(cells)
-    print(lines[n][:200])
-open(path, "w").write("\n".join(lines))
+        extra = " + `k_bev` %.2f" % (a["kernels"]["k_bev"]["avg_us"] / 1e3)
+    rate = lambda r: "%.0f M" % (r["agent_steps_per_s"] / 1e6) if r["agent_steps_per_s"] >= 1e8 else "%.1f M" % (r["agent_steps_per_s"] / 1e6)
+    prev = "← %s ms, %s, %.1f %%" % (f(c["ms_per_step"]), rate(c), 100 * c["roofline"]["frac"]) if c else "← new line (round 3's build: 3.28 ms / 3.65 ms)" if key in ("synthetic_128", "waymo_raw") else ""
+    bold = "**%s**" if key == "synthetic" else "%s"
+    out.append("| %s | %s | %s (%s) | %s (%s) | %s%s | %s (%s) | %s ms%s | %.1f %% | %s |" % (
+        name, mode, bold % f(a["ms_per_step"]), f(b["ms_per_step"]), f(a["ms_per_step_events"]), f(b["ms_per_step_events"]),
+        f(a["kernels_sum_us"] / 1e3), " + `k_pack_obs`, `k_episode_step`" if key == "rl_loop" else "", bold % rate(a), rate(b),
+        ("%.3f" if road < 0.1 else "%.2f") % road, extra, 100 * a["roofline"]["frac"], prev))
+cpu = lineA["cpu_baseline"]
+out.append("| synthetic, CPU port, %d threads / all %d / 1 thread | — | — | — | — | %.3f M / %.3f M / %.3f M | — | — | |" % (
+    cpu["cores"], cpu["host_cores"], cpu["value"] / 1e6, (cpu["all_cores_value"] or 0) / 1e6, cpu["single_thread_value"] / 1e6))
+path = os.path.join(ROOT, "DESIGN.md")
+s = open(path).read()
+b0, b1 = "<!-- results table -->\n", "<!-- /results table -->\n"
+i, j = s.index(b0) + len(b0), s.index(b1)
+open(path, "w").write(s[:i] + "\n".join(out) + "\n" + s[j:])
+print("\n".join(out))
