@@ -38,7 +38,7 @@ for name, key, mode in ROWS:
     if key == "bev":
         extra = " + `k_bev` %.2f" % (a["kernels"]["k_bev"]["avg_us"] / 1e3)
     rate = lambda r: "%.0f M" % (r["agent_steps_per_s"] / 1e6) if r["agent_steps_per_s"] >= 1e8 else "%.1f M" % (r["agent_steps_per_s"] / 1e6)
-    prev = "← %s ms, %s, %.1f %%" % (f(c["ms_per_step"]), rate(c), 100 * c["roofline"]["frac"]) if c else "← new line (round 3's build: 3.28 ms / 3.65 ms)" if key in ("synthetic_128", "waymo_raw") else ""
+    prev = "← %s ms, %s, %.1f %%" % (f(c["ms_per_step"]), rate(c), 100 * c["roofline"]["frac"]) if c else "PLACEHOLDER" if key in ("synthetic_128", "waymo_raw") else ""
     bold = "**%s**" if key == "synthetic" else "%s"
     out.append("| %s | %s | %s (%s) | %s (%s) | %s%s | %s (%s) | %s ms%s | %.1f %% | %s |" % (
         name, mode, bold % f(a["ms_per_step"]), f(b["ms_per_step"]), f(a["ms_per_step_events"]), f(b["ms_per_step_events"]),
