@@ -494,6 +494,9 @@ __device__ __forceinline__ void order_waves(const DevSim &d, int count, unsigned
 // gather neighbouring 32-byte records (the nearest roads come in runs along their polylines) instead of the heap's order
 // (136 -> us for the same 472 MB at 1024 x 64; set order, ascending by construction, always ran at 82) -- and the
 // order only has to exist where the rows are stored.
+#ifndef GD_SET_CELL_ORDER
+#define GD_SET_CELL_ORDER 1
+#endif
 constexpr int ROWS_AB = 5;
 template <int A_T>
 __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
@@ -1071,7 +1074,11 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                 for (int q = lane; q < BMW; q += 64) bits[q] = 0u;
                 wave_sync();
                 if (nin < K) {  // fewer than K roads within the bound: then the bound is the radius, and all of them are selected
+#if GD_SET_CELL_ORDER
+                    for (int j = lane; j < nin; j += 64) out[j] = cidx[j];
+#else
                     for (int j = lane; j < nin; j += 64) atomicOr(&bits[cidx[j] >> 5], 1u << (cidx[j] & 31));
+#endif
                     count = nin;
                 } else {
                     // the K-th smallest key T: largest T with count(key < T) < K.  The candidates' key bits sit in
@@ -1186,6 +1193,47 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                     }
                     // everything below T, then the lowest road indices among the ties at T
                     const int less = count_below(lo);
+#if GD_SET_CELL_ORDER
+                    // The rows leave in the order the candidates were gathered in (grid cell by grid cell, ascending road index
+                    // inside a cell): one ballot and one store per 64 candidates.  (Round 2 marked the selected roads in a bitmap
+                    // of the world's roads and read it back in ascending road index: a zeroing pass, 200 LDS atomics and a
+                    // bit-by-bit loop that runs as long as the fullest word of the wave -- a third of this kernel's
+                    // instructions for an order nobody asked for: the mode's contract is the row SET.)
+                    unsigned int rd[KR];
+#pragma unroll
+                    for (int u = 0; u < KR; u++) rd[u] = u < nu ? (unsigned int)cidx[u * 64 + lane] : 0u;
+                    unsigned int tie_taken = 0u;  // bit u: this lane's candidate u is one of the ties at T that are kept
+                    {
+                        unsigned int floor_idx = 0;  // ties with a road index below this are already taken
+                        for (int t = less; t < K; t++) {  // almost always one iteration
+                            unsigned int best = 0xffffffffu;
+#pragma unroll
+                            for (int u = 0; u < KR; u++)
+                                if (u < nu && kb[u] == lo && rd[u] >= floor_idx) best = min(best, rd[u]);
+                            for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned int)__shfl_xor((int)best, off));
+                            if (best == 0xffffffffu) break;  // cannot happen: at least K candidates have a key <= T
+#pragma unroll
+                            for (int u = 0; u < KR; u++) tie_taken |= (u < nu && kb[u] == lo && rd[u] == best) ? 1u << u : 0u;
+                            floor_idx = best + 1u;
+                        }
+                    }
+                    int base = 0;
+#pragma unroll
+                    for (int u = 0; u < KR; u++) {
+                        if (u < nu) {  // wave-uniform
+                            const bool take = kb[u] < lo || ((tie_taken >> u) & 1u) != 0u;  // (beyond nin: key bits are all ones)
+                            const unsigned long long tb = __ballot(take);
+                            if (take) out[base + __popcll(tb & lower)] = (unsigned short)rd[u];
+                            base += __popcll(tb);
+                        }
+                    }
+                    count = K;
+                    kth = __uint_as_float(lo);
+                }
+                wave_sync();
+            }
+        }
+#else
 #pragma unroll
                     for (int u = 0; u < KR; u++) {
                         if (u < nu && kb[u] < lo) {
@@ -1234,6 +1282,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                 }
             }
         }
+#endif
         if (!done) count = S::select_streaming(d, rxy, R, knn, ex, ey, iw, iz, ckey, cidx, out, lane, kth);
         count = min(count, K);
         if (lane == 0) {
