@@ -486,7 +486,7 @@ def main():
                     help="default: nccl (RCCL); gloo + --single-device rehearses the N>1 path on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--knn-order", type=int, default=0, choices=(0, 1),
-                    help="0 = reference heap order (default, elementwise parity); 1 = same row set, road-index order")
+                    help="0 = reference heap order (default, elementwise parity); 1 = same row set, in the engine's own (grid-cell) order")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as CHILD processes
@@ -540,7 +540,7 @@ def main():
         dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
                          ms_per_step_max_rank=primary["ms_per_step"], ms_per_step_min_rank=primary["ms_per_step_min_rank"])
     if rank == 0:
-        order_txt = {0: "reference heap order", 1: "SET order: same rows, road-index order"}[primary["knn_order"]]
+        order_txt = {0: "reference heap order", 1: "SET order: same rows as a set, grid-cell order"}[primary["knn_order"]]
         line = {
             "metric": "agent-steps/sec at 1024 worlds x 64 agents; achieved HBM GB/s on obs kernel",
             "value": primary["agent_steps_per_s"],

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "engine.hpp"
 #include "gd_math.hpp"
@@ -494,8 +495,8 @@ __device__ __forceinline__ void order_waves(const DevSim &d, int count, unsigned
 // gather neighbouring 32-byte records (the nearest roads come in runs along their polylines) instead of the heap's order
 // (136 -> us for the same 472 MB at 1024 x 64; set order, ascending by construction, always ran at 82) -- and the
 // order only has to exist where the rows are stored.
-#ifndef GD_SET_CELL_ORDER
-#define GD_SET_CELL_ORDER 1
+#ifndef GD_SET_CAP
+#define GD_SET_CAP 1024
 #endif
 constexpr int ROWS_AB = 5;
 template <int A_T>
@@ -864,8 +865,9 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 
 // ---- set-order mode (gd_config.knn_order = GD_KNN_SET_ORDER) ----
 //
-// Same row SET as the reference (the K nearest by (distance^2, road index), then the radius filter), rows in
-// ascending road index instead of the reference's heap-history order.  Because the radius filter runs after the
+// Same row SET as the reference (the K nearest by (distance^2, road index), then the radius filter), rows in the order
+// the candidates are gathered in (grid cell by grid cell, ascending road index inside a cell; the full-stream path:
+// ascending road index) instead of the reference's heap-history order.  Because the radius filter runs after the
 // top-K, the result is "every in-radius road" whenever fewer than K roads are in radius, and the K smallest of the
 // in-radius roads otherwise; no heap is needed.  Each wave takes its agents one at a time, all 64 lanes cooperating:
 //
@@ -881,13 +883,14 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 //   * SELECT, only when more than K candidates: search on the key bits for the K-th smallest key with three probes
 //     per pass (counts packed in one register, one cross-lane reduction); ties at the K-th key go to the lowest road
 //     indices (the reference breaks such ties by heap position, the one documented difference of the set).
-//   * ORDER: the selected roads are marked in a bitmap over the world's road indices and read back in ascending
-//     order (popcount prefix over the lanes), straight into the selection scratch of k_map_rows.
+//   * WRITE-OUT: the selected candidates leave in candidate order, one ballot and one store per 64 of them, straight
+//     into the selection scratch of k_map_rows.  (Rounds 1-3 marked them in a bitmap of the world's roads and read it
+//     back in ascending road index: a third of the kernel for an order the mode does not promise.)
 // The linear scan (AllEntitiesWithRadiusFiltering: first K in index order within the radius) and the rare agent with
 // more candidates than the LDS buffer holds take the full-stream path (select_streaming).
 template <int A_T>
 struct SetSel {
-    static constexpr int CAP = 1024;   // (key, road) candidates a wave holds in LDS
+    static constexpr int CAP = GD_SET_CAP;   // (key, road) candidates a wave holds in LDS
     static constexpr int BMW = 320;    // bitmap words: 10,240 road indices
 
     // Full-stream selection (round 1's kernel): every road of the world, 256 per iteration; candidates recomputed from
@@ -998,7 +1001,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
         const size_t i = (size_t)w * A_T + a;
         const float ex = d.px[i], ey = d.py[i];
         const float iw = d.qw[i], iz = -d.qz[i];  // the INVERSE rotation
-        unsigned short *out = FUSE ? s_sel[wave] : d.sel_idx + i * K;  // the selected road indices, ascending
+        unsigned short *out = FUSE ? s_sel[wave] : d.sel_idx + i * K;  // the selected road indices, in the mode's order
         int count = 0;
         float kth = __builtin_inff();
         bool done = false;
@@ -1074,16 +1077,16 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                 for (int q = lane; q < BMW; q += 64) bits[q] = 0u;
                 wave_sync();
                 if (nin < K) {  // fewer than K roads within the bound: then the bound is the radius, and all of them are selected
-#if GD_SET_CELL_ORDER
                     for (int j = lane; j < nin; j += 64) out[j] = cidx[j];
-#else
-                    for (int j = lane; j < nin; j += 64) atomicOr(&bits[cidx[j] >> 5], 1u << (cidx[j] & 31));
-#endif
                     count = nin;
                 } else {
-                    // the K-th smallest key T: largest T with count(key < T) < K.  The candidates' key bits sit in
-                    // registers (lane l holds candidates l, l + 64, ...).
-                    constexpr int KR = CAP / 64;
+                  // the K-th smallest key T: largest T with count(key < T) < K.  The candidates' key bits sit in
+                  // registers (lane l holds candidates l, l + 64, ...): KR slots.  Two instantiations of the block: five slots
+                  // (320 candidates -- the coherence bound leaves about 240 of them on the bench scene) and all CAP / 64;
+                  // every pass over the slots is unrolled with a guard per slot, and with sixteen slots for four used ones
+                  // the guards, the spilled scalars and the registers of the unused slots were a fifth of the kernel.
+                  auto select = [&](auto slots_tag) {
+                    constexpr int KR = decltype(slots_tag)::value;
                     unsigned int kb[KR];
 #pragma unroll
                     for (int u = 0; u < KR; u++) kb[u] = u * 64 + lane < nin ? __float_as_uint(ckey[u * 64 + lane]) : 0xffffffffu;
@@ -1193,7 +1196,6 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                     }
                     // everything below T, then the lowest road indices among the ties at T
                     const int less = count_below(lo);
-#if GD_SET_CELL_ORDER
                     // The rows leave in the order the candidates were gathered in (grid cell by grid cell, ascending road index
                     // inside a cell): one ballot and one store per 64 candidates.  (Round 2 marked the selected roads in a bitmap
                     // of the world's roads and read it back in ascending road index: a zeroing pass, 200 LDS atomics and a
@@ -1229,60 +1231,13 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                     }
                     count = K;
                     kth = __uint_as_float(lo);
+                  };
+                  if (nin <= 5 * 64) select(std::integral_constant<int, 5>{});
+                  else select(std::integral_constant<int, CAP / 64>{});
                 }
                 wave_sync();
             }
         }
-#else
-#pragma unroll
-                    for (int u = 0; u < KR; u++) {
-                        if (u < nu && kb[u] < lo) {
-                            const unsigned int r = cidx[u * 64 + lane];
-                            atomicOr(&bits[r >> 5], 1u << (r & 31));
-                        }
-                    }
-                    unsigned int floor_idx = 0;  // ties with a road index below this are already taken
-                    for (int t = less; t < K; t++) {  // almost always one iteration
-                        unsigned int best = 0xffffffffu;
-                        for (int j = lane; j < nin; j += 64)
-                            if (__float_as_uint(ckey[j]) == lo && (unsigned int)cidx[j] >= floor_idx) best = min(best, (unsigned int)cidx[j]);
-                        for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned int)__shfl_xor((int)best, off));
-                        if (best == 0xffffffffu) break;  // cannot happen: at least K candidates have a key <= T
-                        if (lane == 0) bits[best >> 5] |= 1u << (best & 31);
-                        floor_idx = best + 1u;
-                        wave_sync();
-                    }
-                    count = K;
-                    kth = __uint_as_float(lo);
-                }
-                wave_sync();
-                // read the bitmap back in ascending road order.  Lane l owns words l, l + 64, ... (neighbouring roads are
-                // selected together, so consecutive words go to different lanes); an inclusive prefix sum over the lanes
-                // per group of 64 words (DPP row shifts and row broadcasts: no LDS round trips) gives every word its place.
-                constexpr int WPL = BMW / 64;
-                int base = 0;
-#pragma unroll
-                for (int q = 0; q < WPL; q++) {
-                    unsigned int m = bits[q * 64 + lane];
-                    const int pre = __popc(m);
-                    int incl = pre;
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-                    int pos = base + incl - pre;
-                    base += __builtin_amdgcn_readlane(incl, 63);
-                    while (m) {
-                        const int bit = __ffs(m) - 1;
-                        m &= m - 1u;
-                        out[pos++] = (unsigned short)((q * 64 + lane) * 32 + bit);
-                    }
-                }
-            }
-        }
-#endif
         if (!done) count = S::select_streaming(d, rxy, R, knn, ex, ey, iw, iz, ckey, cidx, out, lane, kth);
         count = min(count, K);
         if (lane == 0) {

@@ -106,7 +106,7 @@ typedef struct gd_tensor_desc {
 /* How the k-NN road observation orders its rows. */
 enum {
     GD_KNN_REFERENCE_ORDER = 0, /* rows in the reference's SGI-heap array order (src/knn.hpp:103-158) */
-    GD_KNN_SET_ORDER = 1        /* same row SET, ascending road index; NOT elementwise identical */
+    GD_KNN_SET_ORDER = 1        /* same row SET, in a fixed order of the engine's own (grid cell by grid cell); NOT elementwise identical */
 };
 
 /* Manager::Config (src/mgr.hpp:30-44) minus the render fields, plus engine knobs. */
