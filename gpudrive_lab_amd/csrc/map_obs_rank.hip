@@ -23,10 +23,12 @@
 //   k_knn_finish  one wave per agent: ranks back to road indices, radiusFilter (src/knn.hpp:83-97), the checkpoints'
 //                 K-th distances for the next step, hand-over to k_map_rows.
 //
-// An agent without usable checkpoints (first selection after a reset or a map change, a teleport), with more
-// candidates than CAP, with more than 32 equal keys, or in a world with fewer than K roads raises the fallback flag of its
-// group of 32 agents; k_map_obs (map_obs.hip) then selects for that group as before -- the same rows by construction --
-// and records checkpoints, so the group is back on this path at the next step.
+// An agent without a usable bound (first selection after the worlds were built, a logged agent that reappears somewhere else)
+// borrows a neighbour's checkpoints or is bounded afresh inside k_knn_scan; one with more candidates than the standard
+// ranking holds (1272) is ranked by the long-list instantiation (2552).  Only an agent beyond that, with more equal keys than
+// a rank can count (32; long lists 16), or in a world with fewer than K roads (or below rk_min_roads) raises the fallback flag
+// of its group of 32 agents; k_map_obs (map_obs.hip) then selects for that group as before -- the same rows by construction
+// -- and records checkpoints, so the group is back on this path at the next step.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
