@@ -18,6 +18,12 @@
 #include "engine.hpp"
 #include "gd_math.hpp"
 #include "scene.hpp"
+#ifdef GD_CLOCKS
+namespace gd { void set_clocks_read(unsigned long long *out); }
+#endif
+#ifndef GD_GRID_MIN_CELL
+#define GD_GRID_MIN_CELL 16.f
+#endif
 
 namespace {
 
@@ -674,7 +680,7 @@ struct gd_sim {
                 minx = std::min(minx, xy[2 * r]); maxx = std::max(maxx, xy[2 * r]);
                 miny = std::min(miny, xy[2 * r + 1]); maxy = std::max(maxy, xy[2 * r + 1]);
             }
-            const float cell = std::max(16.f, std::max(maxx - minx, maxy - miny) / 64.f + 1e-3f);
+            const float cell = std::max(GD_GRID_MIN_CELL, std::max(maxx - minx, maxy - miny) / 64.f + 1e-3f);
             g.ox = minx; g.oy = miny; g.inv_cell = 1.f / cell;
             g.nx = std::max(1, std::min(64, static_cast<int>((maxx - minx) * g.inv_cell) + 1));
             g.ny = std::max(1, std::min(64, static_cast<int>((maxy - miny) * g.inv_cell) + 1));
@@ -1128,6 +1134,14 @@ int gd_attach_bev(gd_sim *s, float *bev) {
 }
 
 int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
+#ifdef GD_CLOCKS
+    if (s && out && which >= 22 && which <= 29) {  // the set-order selection's phase clocks (map_obs.hip g_set_clk): 22 reads and zeroes all
+        static unsigned long long clk[8];
+        if (which == 22) gd::set_clocks_read(clk);
+        *out = (int64_t)clk[which - 22];
+        return GD_OK;
+    }
+#endif
 #if defined(GD_DIAG) || defined(GD_CLOCKS)
     constexpr int32_t kLastStat = 20;
 #else

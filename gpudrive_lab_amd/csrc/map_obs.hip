@@ -71,6 +71,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Set bits of `b` below this lane's own (v_mbcnt_lo / v_mbcnt_hi: two instructions; popc(b & lower_mask) is four).
+__device__ __forceinline__ int bits_below_lane(unsigned long long b) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)b, 0u));
+}
+
 // Position of column `c` in a row of the u16 index array.  With 64 columns, c and c + 32 share a dword, so the
 // 32 lanes of either half of the wave (the LDS services them separately) touch 32 different banks.
 __device__ __forceinline__ int idx_col(int c) { return AW == 64 ? (c & 31) * 2 + (c >> 5) : c; }
@@ -891,7 +896,7 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 template <int A_T>
 struct SetSel {
     static constexpr int CAP = GD_SET_CAP;   // (key, road) candidates a wave holds in LDS
-    static constexpr int BMW = 320;    // bitmap words: 10,240 road indices
+    static constexpr int BMW = 256;    // words of the key histogram (and, before it, of the gather's piece list)
 
     // Full-stream selection (round 1's kernel): every road of the world, 256 per iteration; candidates recomputed from
     // the stream when they do not fit the buffer.  Writes the selected road indices, ascending, to out[0..count).
@@ -967,8 +972,26 @@ struct SetSel {
     }
 };
 
+#ifndef GD_SET_ABL
+#define GD_SET_ABL 0
+#endif
+#ifndef GD_SET_PB
+#define GD_SET_PB 2  // pieces of the grid rows' runs requested together (k_map_obs_set)
+#endif
+#ifdef GD_CLOCKS
+// -DGD_CLOCKS builds (tools/build_expt.sh clk -DGD_CLOCKS; tools/set_phases.py): clock ticks per phase of the set-order
+// selection summed over the waves (gd_stat 22..29): 0 prologue, 1 gather, 2 key registers + histogram, 3 K-th key,
+// 4 ties + write-out, 5 header; 6 = gather iterations, 7 = candidates
+__device__ unsigned long long g_set_clk[8];
+#define SET_PHASE(n) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk_sum[n] += (unsigned int)(t_ - clk_prev); clk_prev = t_; } while (0)
+#else
+#define SET_PHASE(n) do {} while (0)
+#endif
+#ifndef GD_SET_WPE
+#define GD_SET_WPE 4
+#endif
 template <int A_T, int NW, bool FUSE>
-__global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_WPE))) void k_map_obs_set(DevSim d) {
     using S = SetSel<A_T>;
     constexpr int CAP = S::CAP, BMW = S::BMW;
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
@@ -997,88 +1020,172 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
 
     // a workgroup takes NW * set_apw consecutive agents of its world (set_groups), each wave set_apw of them
     const int a_first = (wg & 255) * (NW * d.set_apw), a_end = min(n, a_first + NW * d.set_apw);
+#ifdef GD_CLOCKS
+    unsigned int clk_sum[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    unsigned long long clk_prev = __builtin_amdgcn_s_memtime();
+#endif
+    // The selection is a chain of memory round trips (pose -> the grid rows' runs -> the pieces of those runs), and with
+    // four waves per SIMD nothing else covers them: what an agent needs is requested while the one before it is still
+    // being worked on (pose and last step's bound at the top of the previous agent, the runs before its K-th-key search),
+    // and the pieces of a run are requested GD_SET_PB at a time, the next batch before the current one is keyed.
+    struct AgentIn { float ex, ey, qw, qz; float4 pv; };
+    struct Plan { float bound, floor_key; int nrows, run_lo, run_hi; };
+    const bool use_grid = knn && R > 0;
+    auto load_agent = [&](int a) -> AgentIn {
+        const size_t i = (size_t)w * A_T + a;
+        return AgentIn{d.px[i], d.py[i], d.qw[i], d.qz[i], d.knn_prev[i]};
+    };
+    // candidates: within the radius AND within what the previous selection allows (the K-th distance is 1-Lipschitz in the
+    // agent's position: it also cannot fall below sqrt(T) - |movement|, which gives the search for the new T a narrow
+    // starting interval); the rows of the grid the bound's box crosses (a slightly larger box: cells are chosen in plain
+    // float) and the run of every such row (lane q holds row cy0 + q; the grid has at most 64 rows).  Roads left of column
+    // 0 / right of the last column were clamped into the border cells at build time; an agent outside the grid reaches
+    // them through the clamped cell range.
+    // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: every use below carries a 1e-4 margin
+    auto fast_sqrt = [](float x) -> float { return __builtin_amdgcn_sqrtf(x); };
+    const float cell_size = 1.f / g.inv_cell;
+    auto plan = [&](const AgentIn &in) -> Plan {
+        Plan pl{kmax, 0.f, 0, 0, 0};
+        const float4 pv = in.pv;
+        if (pv.z < __builtin_inff()) {
+            const float dx = in.ex - pv.x, dy = in.ey - pv.y;
+            const float move = fast_sqrt(dx * dx + dy * dy);
+            const float reach = fast_sqrt(pv.z) * 1.0001f + move * 1.0001f + 1e-3f;
+            pl.bound = fminf(pl.bound, reach * reach * 1.0001f);
+            const float near = fast_sqrt(pv.z) * 0.9999f - move * 1.0001f - 1e-3f;
+            pl.floor_key = near > 0.f ? near * near * 0.9999f : 0.f;
+        }
+        const float rr = fast_sqrt(pl.bound) * 1.001f + 1e-2f;
+        const int cy0 = max(0, min(g.ny - 1, (int)floorf((in.ey - rr - g.oy) * g.inv_cell)));
+        const int cy1 = max(0, min(g.ny - 1, (int)floorf((in.ey + rr - g.oy) * g.inv_cell)));
+        pl.nrows = cy1 - cy0 + 1;
+        // lane q: row cy0 + q, cut to the chord of the bound's circle at the edge of the row nearer to the agent (the box
+        // holds 4 / pi times the circle's roads); lanes beyond the box read a row of the grid all the same (no branch
+        // around the loads)
+        const int row = min(cy0 + lane, g.ny - 1);
+        const float band_lo = g.oy + (float)row * cell_size, band_hi = band_lo + cell_size;
+        const float dy = fmaxf(fmaxf(band_lo - in.ey, in.ey - band_hi) - 1e-2f, 0.f);
+        const float hw = fast_sqrt(fmaxf(rr * rr - dy * dy, 0.f)) * 1.001f + 1e-2f;
+        const int cx0 = max(0, min(g.nx - 1, (int)floorf((in.ex - hw - g.ox) * g.inv_cell)));
+        const int cx1 = max(0, min(g.nx - 1, (int)floorf((in.ex + hw - g.ox) * g.inv_cell)));
+        pl.run_lo = coff[row * g.nx + cx0];
+        pl.run_hi = coff[row * g.nx + cx1 + 1];
+        return pl;
+    };
+    AgentIn nx{0.f, 0.f, 1.f, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    Plan npl{kmax, 0.f, 0, 0, 0};
+    if (a_first + wave < a_end) {
+        nx = load_agent(a_first + wave);
+        if (use_grid) npl = plan(nx);
+    }
     for (int a = a_first + wave; a < a_end; a += NW) {  // wave-uniform
         const size_t i = (size_t)w * A_T + a;
-        const float ex = d.px[i], ey = d.py[i];
-        const float iw = d.qw[i], iz = -d.qz[i];  // the INVERSE rotation
+        const AgentIn cur_in = nx;
+        const Plan pl = npl;
+        const bool more = a + NW < a_end;
+        if (more) nx = load_agent(a + NW);
+        const float ex = cur_in.ex, ey = cur_in.ey;
+        const float iw = cur_in.qw, iz = -cur_in.qz;  // the INVERSE rotation
         unsigned short *out = FUSE ? s_sel[wave] : d.sel_idx + i * K;  // the selected road indices, in the mode's order
         int count = 0;
         float kth = __builtin_inff();
         bool done = false;
-        if (knn && R > 0) {
-            // candidates: within the radius AND within what the previous selection allows
-            // (the K-th distance is 1-Lipschitz in the agent's position: it also cannot fall below sqrt(T) - |movement|,
-            // which gives the search for the new T a narrow starting interval)
-            const float4 pv = d.knn_prev[i];
-            float bound = kmax, floor_key = 0.f;
-            if (pv.z < __builtin_inff()) {
-                const float dx = ex - pv.x, dy = ey - pv.y;
-                const float move = sqrtf(dx * dx + dy * dy);
-                const float reach = sqrtf(pv.z) * 1.0001f + move * 1.0001f + 1e-3f;
-                bound = fminf(bound, reach * reach * 1.0001f);
-                const float near = sqrtf(pv.z) * 0.9999f - move * 1.0001f - 1e-3f;
-                floor_key = near > 0.f ? near * near * 0.9999f : 0.f;
-            }
-            // rows of the grid the bound's box crosses (a slightly larger box: cells are chosen in plain float)
-            const float rr = sqrtf(bound) * 1.001f + 1e-2f;
-            const int cx0 = max(0, min(g.nx - 1, (int)floorf((ex - rr - g.ox) * g.inv_cell)));
-            const int cx1 = max(0, min(g.nx - 1, (int)floorf((ex + rr - g.ox) * g.inv_cell)));
-            const int cy0 = max(0, min(g.ny - 1, (int)floorf((ey - rr - g.oy) * g.inv_cell)));
-            const int cy1 = max(0, min(g.ny - 1, (int)floorf((ey + rr - g.oy) * g.inv_cell)));
-            // roads left of column 0 / right of the last column were clamped into the border cells at build time; an
-            // agent outside the grid reaches them through the clamped cell range
-            // the run of every grid row, fetched in one go (lane q holds row cy0 + q; the grid has at most 64 rows)
-            const int nrows = cy1 - cy0 + 1;
-            int run_lo = 0, run_hi = 0;
-            if (lane < nrows) {
-                run_lo = coff[(cy0 + lane) * g.nx + cx0];
-                run_hi = coff[(cy0 + lane) * g.nx + cx1 + 1];
-            }
-            // One coalesced 64-road piece per iteration, (index, x, y) from the cell-sorted copies; the next piece is
-            // requested before the current one is keyed.
-            int nin = 0, q = 0;
-            int j0 = __builtin_amdgcn_readlane(run_lo, 0), j1 = __builtin_amdgcn_readlane(run_hi, 0), jb = j0;
-            auto settle = [&]() {  // move (q, jb) to the next non-empty piece; q == nrows when there is none
-                while (q < nrows && jb >= j1) {
-                    q++;
-                    if (q < nrows) {
-                        j0 = __builtin_amdgcn_readlane(run_lo, q);
-                        j1 = __builtin_amdgcn_readlane(run_hi, q);
-                        jb = j0;
-                    }
-                }
-            };
-            auto fetch = [&](int &r, float2 &xy, bool &ok) {
-                const int j = jb + lane;
-                ok = q < nrows && j < j1;
-                r = ok ? (int)citems[j] : 0;
-                xy = ok ? cxy[j] : make_float2(0.f, 0.f);
-            };
-            settle();
-            int r_cur, r_nxt;
-            float2 xy_cur, xy_nxt;
-            bool ok_cur, ok_nxt;
-            fetch(r_cur, xy_cur, ok_cur);
-            while (q < nrows) {
-                jb += 64;
-                settle();
-                fetch(r_nxt, xy_nxt, ok_nxt);
-                const float key = ego_dist2(ex, ey, iw, iz, xy_cur.x, xy_cur.y);
-                const bool in = ok_cur && key <= bound;
-                const unsigned long long b = __ballot(in);
-                const int pos = nin + __popcll(b & lower);
-                if (in && pos < CAP) { ckey[pos] = key; cidx[pos] = (unsigned short)r_cur; }
-                nin += __popcll(b);
-                r_cur = r_nxt; xy_cur = xy_nxt; ok_cur = ok_nxt;
+        if (use_grid) {
+            const float bound = pl.bound, floor_key = pl.floor_key;
+            const int nrows = pl.nrows;
+            const int run_lo = pl.run_lo, run_hi = pl.run_hi;
+            // The rows' runs are cut into units of up to 32 consecutive roads (a row of the box holds about that many on the
+            // bench scene: 64-road pieces were half empty); the list of units (first item | length << 16) is laid out in LDS
+            // by the lanes that hold the rows (lane q: row q), and a piece is two units, one per half of the wave: the gather
+            // loop is a plain count over pieces with nothing to decide in it.  (index, x, y) come from the cell-sorted
+            // copies, PB pieces are requested together into one of two register sets, and every load is unconditional (a
+            // unit past the end reads item 0) so that the waits count loads instead of draining them.
+            constexpr int PB = GD_SET_PB;
+            constexpr int UMAX = BMW;  // units the list holds (it borrows the histogram's words, which are zeroed after the gather)
+            unsigned int *unit = bits;
+            int nunits;
+            {
+                const int len = lane < nrows ? max(run_hi - run_lo, 0) : 0;
+                const int nu_row = (len + 31) >> 5;
+                int incl = nu_row;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+                nunits = __builtin_amdgcn_readlane(incl, 63);
+                const int base = incl - nu_row;
+                for (int k = 0; k < nu_row && base + k < UMAX; k++)
+                    unit[base + k] = (unsigned int)(run_lo + 32 * k) | (unsigned int)min(32, len - 32 * k) << 16;
             }
             wave_sync();
+            const int npieces = (nunits + 1) >> 1;
+            const int half = lane >> 5;
+            const unsigned int hl = (unsigned int)(lane & 31);
+            int nin = 0;
+            struct Batch { unsigned int r[PB]; float2 xy[PB]; unsigned int left[PB]; };  // left: roads of this lane's unit, 0 = none
+            auto issue = [&](Batch &bt, int p0) {
+#pragma unroll
+                for (int u = 0; u < PB; u++) {
+                    const int ui = 2 * (p0 + u) + half;
+                    const unsigned int ds = ui < nunits ? unit[ui] : 0u;
+                    bt.left[u] = ds >> 16;
+                    const unsigned int j = (ds & 0xffffu) + min(hl, max(ds >> 16, 1u) - 1u);
+                    bt.r[u] = citems[j];
+                    bt.xy[u] = cxy[j];
+                }
+            };
+            auto take = [&](const Batch &bt) {
+#pragma unroll
+                for (int u = 0; u < PB; u++) {
+                    const float key = ego_dist2(ex, ey, iw, iz, bt.xy[u].x, bt.xy[u].y);
+                    const bool in = hl < bt.left[u] && key <= bound;
+                    const unsigned long long b = __ballot(in);
+                    const int pos = nin + bits_below_lane(b);
+                    if (in && pos < CAP) { ckey[pos] = key; cidx[pos] = (unsigned short)bt.r[u]; }
+                    nin += __popcll(b);
+                }
+            };
+            SET_PHASE(0);
+#if GD_SET_ABL == 2  // timing-only builds: the gather twice (the same candidates again), to read its cost off the counters
+            for (int rep = 0; rep < 2; rep++) {
+                nin = 0;
+                asm volatile("" ::: "memory");
+#endif
+            if (nunits <= UMAX) {
+                Batch ba, bb;
+                issue(ba, 0);
+                for (int p0 = 0; p0 < npieces; p0 += 2 * PB) {
+                    issue(bb, p0 + PB);
+                    take(ba);
+                    if (p0 + PB >= npieces) break;
+                    issue(ba, p0 + 2 * PB);
+                    take(bb);
+                }
+            } else {
+                nin = CAP + 1;  // more units than the list holds: the full-stream path
+            }
+#if GD_SET_ABL == 2
+            }
+#endif
+#ifdef GD_CLOCKS
+            clk_sum[6] += (unsigned int)npieces;
+#endif
+            // the next agent's runs: they arrive while this one's K-th key is searched for
+            if (more) npl = plan(nx);
+            wave_sync();
+            SET_PHASE(1);
+#ifdef GD_CLOCKS
+            clk_sum[7] += (unsigned int)nin;
+#endif
             if (nin <= CAP) {
                 done = true;
-                for (int q = lane; q < BMW; q += 64) bits[q] = 0u;
+                reinterpret_cast<uint4 *>(bits)[lane] = make_uint4(0u, 0u, 0u, 0u);  // the histogram's words
                 wave_sync();
-                if (nin < K) {  // fewer than K roads within the bound: then the bound is the radius, and all of them are selected
-                    for (int j = lane; j < nin; j += 64) out[j] = cidx[j];
-                    count = nin;
+                if (nin < K || GD_SET_ABL == 1) {  // fewer than K roads within the bound: then the bound is the radius, and all of them are selected
+                    for (int j = lane; j < min(nin, K); j += 64) out[j] = cidx[j];
+                    count = min(nin, K);
                 } else {
                   // the K-th smallest key T: largest T with count(key < T) < K.  The candidates' key bits sit in
                   // registers (lane l holds candidates l, l + 64, ...): KR slots.  Two instantiations of the block: five slots
@@ -1139,6 +1246,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                         if (before + (int)h.x < K) { before += (int)h.x; jb = 1;
                             if (before + (int)h.y < K) { before += (int)h.y; jb = 2;
                                 if (before + (int)h.z < K) { before += (int)h.z; jb = 3; } } }
+                        SET_PHASE(2);
                         const unsigned long long cross = __ballot(excl < K && incl >= K);  // exactly one lane: nin >= K
                         const int L = __ffsll((long long)cross) - 1;
                         const int bucket = 4 * L + __builtin_amdgcn_readlane(jb, L);
@@ -1195,6 +1303,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                         }
                     }
                     // everything below T, then the lowest road indices among the ties at T
+                    SET_PHASE(3);
                     const int less = count_below(lo);
                     // The rows leave in the order the candidates were gathered in (grid cell by grid cell, ascending road index
                     // inside a cell): one ballot and one store per 64 candidates.  (Round 2 marked the selected roads in a bitmap
@@ -1204,10 +1313,25 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                     unsigned int rd[KR];
 #pragma unroll
                     for (int u = 0; u < KR; u++) rd[u] = u < nu ? (unsigned int)cidx[u * 64 + lane] : 0u;
-                    unsigned int tie_taken = 0u;  // bit u: this lane's candidate u is one of the ties at T that are kept
-                    {
-                        unsigned int floor_idx = 0;  // ties with a road index below this are already taken
-                        for (int t = less; t < K; t++) {  // almost always one iteration
+                    int nties = 0;
+#pragma unroll
+                    for (int u = 0; u < KR; u++)
+                        if (u < nu) nties += __popcll(__ballot(kb[u] == lo));
+                    int base = 0;
+                    if (less + nties == K) {  // every candidate at T is kept (one candidate at T, as a rule): key <= T is the whole test
+#pragma unroll
+                        for (int u = 0; u < KR; u++) {
+                            if (u < nu) {  // wave-uniform
+                                const bool take = kb[u] <= lo;  // (beyond nin: key bits are all ones)
+                                const unsigned long long tb = __ballot(take);
+                                if (take) out[base + bits_below_lane(tb)] = (unsigned short)rd[u];
+                                base += __popcll(tb);
+                            }
+                        }
+                    } else {
+                        unsigned int tie_taken = 0u;  // bit u: this lane's candidate u is one of the ties at T that are kept
+                        unsigned int floor_idx = 0;   // ties with a road index below this are already taken
+                        for (int t = less; t < K; t++) {
                             unsigned int best = 0xffffffffu;
 #pragma unroll
                             for (int u = 0; u < KR; u++)
@@ -1218,24 +1342,28 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
                             for (int u = 0; u < KR; u++) tie_taken |= (u < nu && kb[u] == lo && rd[u] == best) ? 1u << u : 0u;
                             floor_idx = best + 1u;
                         }
-                    }
-                    int base = 0;
 #pragma unroll
-                    for (int u = 0; u < KR; u++) {
-                        if (u < nu) {  // wave-uniform
-                            const bool take = kb[u] < lo || ((tie_taken >> u) & 1u) != 0u;  // (beyond nin: key bits are all ones)
-                            const unsigned long long tb = __ballot(take);
-                            if (take) out[base + __popcll(tb & lower)] = (unsigned short)rd[u];
-                            base += __popcll(tb);
+                        for (int u = 0; u < KR; u++) {
+                            if (u < nu) {  // wave-uniform
+                                const bool take = kb[u] < lo || ((tie_taken >> u) & 1u) != 0u;
+                                const unsigned long long tb = __ballot(take);
+                                if (take) out[base + bits_below_lane(tb)] = (unsigned short)rd[u];
+                                base += __popcll(tb);
+                            }
                         }
                     }
                     count = K;
                     kth = __uint_as_float(lo);
                   };
+#if GD_SET_ABL == 3  // timing-only builds: the selection twice
+                  if (nin <= 5 * 64) select(std::integral_constant<int, 5>{});
+                  asm volatile("" ::: "memory");
+#endif
                   if (nin <= 5 * 64) select(std::integral_constant<int, 5>{});
                   else select(std::integral_constant<int, CAP / 64>{});
                 }
                 wave_sync();
+                SET_PHASE(4);
             }
         }
         if (!done) count = S::select_streaming(d, rxy, R, knn, ex, ey, iw, iz, ckey, cidx, out, lane, kth);
@@ -1245,6 +1373,7 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
             if (!FUSE) write_header(d, i, ex, ey, iw, -iz, count, r0);
         }
         wave_sync();
+        SET_PHASE(5);
         if (!FUSE) continue;  // k_map_rows writes the rows
         // ---- FUSE: the agent's K rows, written by the wave that selected them.  With several generations of workgroups
         // (many worlds) the HBM-bound row stores of one workgroup overlap the issue-bound selection of the others; when every
@@ -1275,9 +1404,22 @@ __global__ __launch_bounds__(NW * 64) void k_map_obs_set(DevSim d) {
             wave_sync();
         }
     }
+#ifdef GD_CLOCKS
+    if (lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&g_set_clk[k], (unsigned long long)clk_sum[k]);
+#endif
 }
 
 }  // namespace
+
+#ifdef GD_CLOCKS
+void set_clocks_read(unsigned long long *out) {  // and zero them
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_set_clk), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_set_clk), z, sizeof(z));
+}
+#endif
 
 void launch_map_obs(const DevSim &d, hipStream_t st) {
     if (d.knn_order == GD_KNN_SET_ORDER) {

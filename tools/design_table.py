@@ -17,6 +17,8 @@ def load(f):
 A, lineA = load("r04_bench_driver_command.json")
 B, _ = load("r04_bench_default.json")
 C, _ = load("r03_bench_driver_command.json")
+# not in round 3's line: timed this round on the build the round began with (gpurun_out of the first bench call)
+EARLY = {"synthetic_128": "← 3.28 ms (this round's first build)", "waymo_raw": "← 3.65 ms (this round's first build)"}
 ROWS = [("synthetic exact-64, R = 4096 (primary)", "synthetic", "reference order"),
         ("Waymo tiles (35,489 live agents, 6.5 K with roads in reach)", "waymo", "reference order"),
         ("Waymo tiles, 4096 worlds, AgentStop + goal reward (config 3)", "cfg3", "reference order"),
@@ -38,7 +40,7 @@ for name, key, mode in ROWS:
     if key == "bev":
         extra = " + `k_bev` %.2f" % (a["kernels"]["k_bev"]["avg_us"] / 1e3)
     rate = lambda r: "%.0f M" % (r["agent_steps_per_s"] / 1e6) if r["agent_steps_per_s"] >= 1e8 else "%.1f M" % (r["agent_steps_per_s"] / 1e6)
-    prev = "← %s ms, %s, %.1f %%" % (f(c["ms_per_step"]), rate(c), 100 * c["roofline"]["frac"]) if c else "PLACEHOLDER" if key in ("synthetic_128", "waymo_raw") else ""
+    prev = "← %s ms, %s, %.1f %%" % (f(c["ms_per_step"]), rate(c), 100 * c["roofline"]["frac"]) if c else EARLY.get(key, "")
     bold = "**%s**" if key == "synthetic" else "%s"
     out.append("| %s | %s | %s (%s) | %s (%s) | %s%s | %s (%s) | %s ms%s | %.1f %% | %s |" % (
         name, mode, bold % f(a["ms_per_step"]), f(b["ms_per_step"]), f(a["ms_per_step_events"]), f(b["ms_per_step_events"]),
