@@ -737,7 +737,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     if (GD_DIAG_IS(d.rk_dbg, 4)) return;
     const unsigned short *cur16 = reinterpret_cast<const unsigned short *>(L.cnt2);  // cursor of bucket b = its END
     // Candidates with a smaller key = those of the earlier buckets + the smaller ones of the own bucket.  The pass is a chain
-    // of LDS round trips with little to issue in between, so it reads generously: the first eight members of every bucket at
+    // of LDS round trips with little to issue in between, so it reads generously: the first six members of every bucket at
     // once (most hold one or two), then four more per trip while any lane's bucket has members left.  Only keys are read;
     // candidates that met their own key more than once (equal keys, rare) get their place among those afterwards.
     // (a candidate's rank e replaces its bucket in the upper half of the road-index register: registers decide how many
@@ -745,7 +745,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
     unsigned int eqmask = 0u;  // bit g: candidate g of this lane shares its key with another candidate
     float *const kt_row = G::LONG ? d.rk_kt_long + (size_t)uni(in.li) * G::KTN : d.rk_kt + (size_t)i * G::KTN;
     if (lane == 0) kt_row[(nin + 15) >> 4] = kmax_seen;  // behind the last multiple of 16: the largest key
-    constexpr int U = 4, M = 8, STEP = 4;
+    constexpr int U = 4, M = 6, STEP = 4;  // (M = 8: 399 us, 6: 391, 4: 405 -- two instructions per member read and key)
     // A read past the end of the own bucket meets keys of later buckets, which are larger (the bucket function is monotone)
     // and so count neither as smaller nor as equal: no bounds test per member.  Past the last candidate it meets +inf.
     // Past the last candidate: eight entries of +inf, so that the first M members are read at constant offsets from the
