@@ -1273,6 +1273,12 @@ __global__ __launch_bounds__(256) void k_knn_finish(DevSim d) {
     const uint2 spc4 = GD_NT_FINISH_LOAD ? stream_load(reinterpret_cast<const uint2 *>(d.rk_spc + (size_t)i * SPL) + lane) : reinterpret_cast<const uint2 *>(d.rk_spc + (size_t)i * SPL)[lane];
     const unsigned int cp_e = d.rk_cpe[(size_t)i * NCP + min(lane, NCP - 1)];
     const unsigned short cp_r = d.cp_road[(size_t)i * NCP + min(lane, NCP - 1)];
+    // (the compiler otherwise sinks each of these loads below the early returns that do not need it: flag, branch, count,
+    // branch, the rest -- three round trips instead of one.  Naming them all as inputs here keeps them together above the
+    // first branch)
+    static_assert(NP == 4, "operand list");
+    asm volatile("" ::"v"(fell_back), "v"(packed), "v"(ex), "v"(ey), "v"(qw), "v"(qz), "v"(steps_left), "v"(long_slot), "v"(hpair[0]),
+                 "v"(hpair[1]), "v"(hpair[2]), "v"(hpair[3]), "v"(spc4.x), "v"(spc4.y), "v"(cp_e), "v"(cp_r), "s"(r0), "s"(r1));
     if (li >= ranked_agents || fell_back != 0) return;  // beyond the order / k_map_obs selects for this group
     // (agents out of reach of every road never get here: k_knn_scan wrote their empty hand-over)
     const int n = packed & 0xffff, nle = (packed >> 16) & 0xfff;
