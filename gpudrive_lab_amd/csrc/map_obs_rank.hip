@@ -1093,9 +1093,9 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
                 n_ins++;
 #endif
                 // pop_heap: the hole goes from the root to the bottom of the (K - 1)-element heap along the larger child.
-                // Levels 0 and 1 are decided in registers (slots 1..7 live there during the replay); below that two levels
-                // per LDS round trip: a node's children pair and both grandchildren pairs are fetched together (pairs beyond
-                // the heap hold 0, which loses every comparison).  The ancestors of slot K that the push will meet are
+                // Levels 0 and 1 are decided in registers (slots 1..7 live there during the replay); below that three, then two
+                // levels per LDS round trip: a node's children pair, its grandchildren pairs (and great-grandchildren pairs)
+                // are fetched together (pairs beyond the heap hold 0, which loses every comparison).  The ancestors of slot K that the push will meet are
                 // requested now as well and patched where the pop's path went through them.
                 int g[8];
                 unsigned int ck[7];
@@ -1107,21 +1107,33 @@ __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
                 g[1] = 2 + (right0 ? 1 : 0);
                 g[2] = 2 * g[1] + (right1 ? 1 : 0);
                 const unsigned int q12 = H.get(12), q25 = H.get(25), q50 = H.get(50), q100 = H.get(100);
-#pragma unroll
-                for (int l = 2; l < 6; l += 2) {
-                    const unsigned int pc = H.pair(g[l]), pl = H.pair(2 * g[l]), pr2 = H.pair(2 * g[l] + 1);
-                    bool right, right2;
-                    ck[l] = larger(pc & 0xffffu, pc >> 16, right);
-                    g[l + 1] = 2 * g[l] + (right ? 1 : 0);
-                    const unsigned int pg = right ? pr2 : pl;
-                    ck[l + 1] = larger(pg & 0xffffu, pg >> 16, right2);
-                    g[l + 2] = 2 * g[l + 1] + (right2 ? 1 : 0);
+                // (two round trips: three levels below slot g[2] -- its children pair, both grandchildren pairs and all four
+                // great-grandchildren pairs, seven dwords at constant offsets from one address -- then two levels below
+                // g[5].  Round 3 and the first half of round 4 went two, two and one level: a round trip more per insert,
+                // and the inserts of the agent with the most candidates are the kernel's duration: 452 -> 435 us)
+                {
+                    const int g2 = g[2];
+                    const unsigned int pc = H.pair(g2), pl = H.pair(2 * g2), pr2 = H.pair(2 * g2 + 1);
+                    const unsigned int p0 = H.pair(4 * g2), p1 = H.pair(4 * g2 + 1), p2 = H.pair(4 * g2 + 2), p3 = H.pair(4 * g2 + 3);
+                    bool ra, rb, rc;
+                    ck[2] = larger(pc & 0xffffu, pc >> 16, ra);
+                    g[3] = 2 * g2 + (ra ? 1 : 0);
+                    const unsigned int pg = ra ? pr2 : pl;
+                    ck[3] = larger(pg & 0xffffu, pg >> 16, rb);
+                    g[4] = 2 * g[3] + (rb ? 1 : 0);
+                    const unsigned int pa = rb ? p1 : p0, pb = rb ? p3 : p2;
+                    const unsigned int pgg = ra ? pb : pa;
+                    ck[4] = larger(pgg & 0xffffu, pgg >> 16, rc);
+                    g[5] = 2 * g[4] + (rc ? 1 : 0);
                 }
                 {
-                    const unsigned int pc = H.pair(g[6]);
-                    bool right;
-                    ck[6] = larger(pc & 0xffffu, pc >> 16, right);
-                    g[7] = 2 * g[6] + (right ? 1 : 0);
+                    const unsigned int pc = H.pair(g[5]), pl = H.pair(2 * g[5]), pr2 = H.pair(2 * g[5] + 1);
+                    bool ra, rb;
+                    ck[5] = larger(pc & 0xffffu, pc >> 16, ra);
+                    g[6] = 2 * g[5] + (ra ? 1 : 0);
+                    const unsigned int pg = ra ? pr2 : pl;
+                    ck[6] = larger(pg & 0xffffu, pg >> 16, rb);
+                    g[7] = 2 * g[6] + (rb ? 1 : 0);
                 }
                 // the old last element climbs back from the leaf hole past every moved child that is smaller; the moved
                 // children are non-increasing down the path, so "it passes level l" is monotone in l and the value that
