@@ -1101,6 +1101,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
             // copies, PB pieces are requested together into one of two register sets, and every load is unconditional (a
             // unit past the end reads item 0) so that the waits count loads instead of draining them.
             constexpr int PB = GD_SET_PB;
+            static_assert(GD_MAX_ROAD_ENTITIES < 65536, "a unit's first item in 16 bits");
             constexpr int UMAX = BMW;  // units the list holds (it borrows the histogram's words, which are zeroed after the gather)
             unsigned int *unit = bits;
             int nunits;
