@@ -586,7 +586,7 @@ __device__ __forceinline__ void rank_agent(const DevSim &d, const RankIn &in, in
         }
     }
     wave_sync();
-    // the agent's place in the replay order (k_knn_bins / k_knn_order: most candidates first).  Taken now: the counter's
+    // the agent's place in the replay order (k_knn_order: most candidates first).  Taken now: the counter's
     // answer is a trip to the L2 and back that nothing has to wait for until the agent is done
     const int bin = 255 - min(255, (nin - K) / 5);
     int ticket = 0;
@@ -949,41 +949,43 @@ struct RankHeap {
 };
 
 // Replay order: the agents on the rank path sorted by candidate count, longest first (counting sort over 256 bins: k_knn_rank
-// takes a ticket in its bin, this kernel turns the bin counts into starts, k_knn_order places the agents).  A wave's rounds are
-// its longest agent's, so agents of similar length share a wave; which wave an agent rides never changes its result.
-__global__ __launch_bounds__(256) void k_knn_bins(DevSim d) {
+// takes a ticket in its bin, every workgroup of this kernel turns the bin counts into starts for itself -- 256 loads and a
+// scan, cheaper than the kernel boundary that a launch of its own for them cost -- and places its agents).  A wave's rounds
+// are its longest agent's, so agents of similar length share a wave; which wave an agent rides never changes its result.
+// The bin counts stay as they are until k_knn_replay's first workgroup zeroes them for the next selection: every
+// workgroup here reads them.
+__global__ __launch_bounds__(256) void k_knn_order(DevSim d) {
     if (d.gate_any && *d.any_reset == 0) return;
     __shared__ int s_part[4];
-    const int t = threadIdx.x;
-    const int c = d.rk_hist[t];
+    __shared__ int s_start[256];
+    const int tl = threadIdx.x;
+    const int c = d.rk_hist[tl];
     const int incl = wave_incl_scan(c);
-    if ((t & 63) == 63) s_part[t >> 6] = incl;
+    if ((tl & 63) == 63) s_part[tl >> 6] = incl;
     __syncthreads();
     int before = 0;
-    for (int k = 0; k < (t >> 6); k++) before += s_part[k];
-    d.rk_hist[256 + t] = before + incl - c;  // start of bin t
-    d.rk_hist[t] = 0;                        // ready for the next selection
-    if (t == 255) {
+    for (int k = 0; k < (tl >> 6); k++) before += s_part[k];
+    s_start[tl] = before + incl - c;  // start of bin tl
+    if (blockIdx.x == 0 && tl == 255) {
         d.rk_hist[512] = before + incl;  // agents on the rank path
         d.rk_hist[513]++;                // selections so far (k_knn_scan staggers the retries of bypassing groups with it)
         for (int x = 0; x < 8; x++) d.rk_hist[528 + x] = 0;  // the next selection's lists of ranked agents start empty
         d.rk_hist[GD_RH_LONG] = 0;
     }
-}
-
-__global__ __launch_bounds__(256) void k_knn_order(DevSim d) {
-    if (d.gate_any && *d.any_reset == 0) return;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    __syncthreads();
+    const int t = blockIdx.x * 256 + tl;
     if (t >= d.live_count) return;
     const int i = d.live_list[t];
     const int ticket = d.rk_ticket[i];
     if (ticket < 0) return;  // not on the rank path
-    d.rk_order[audited(d, d.rk_hist[256 + ((ticket >> 20) & 255)] + (ticket & 0xfffff), d.W * d.A)] = i;
+    d.rk_order[audited(d, s_start[(ticket >> 20) & 255] + (ticket & 0xfffff), d.W * d.A)] = i;
 }
 
 __global__ __launch_bounds__(64) void k_knn_replay(DevSim d) {
     if (d.gate_any && *d.any_reset == 0) return;
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0)  // the bin counts of this selection have been read by every workgroup of k_knn_order: ready for the next
+        for (int k = 0; k < 4; k++) d.rk_hist[k * 64 + lane] = 0;
     const int li = blockIdx.x * AWR + lane;
     constexpr int NPAIR = 128;  // pairs 0..K/2 hold the heap; K/2 + 1 .. 127 stay 0: the "children" of slots beyond the heap
     __shared__ unsigned int s_pair[NPAIR * AWR];
@@ -1449,7 +1451,6 @@ void launch_map_obs_rank(const DevSim &d, hipStream_t st) {
         hipLaunchKernelGGL((k_knn_rank<128, CAP>), gr, dim3(64), 0, st, d);
         if (d.rk_nlong > 0) hipLaunchKernelGGL((k_knn_rank<128, CAP_LONG>), glong, dim3(64), 0, st, d);
     }
-    hipLaunchKernelGGL(k_knn_bins, dim3(1), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_knn_order, dim3((d.live_count + 255) / 256), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_knn_replay, dim3((d.live_count + AWR - 1) / AWR), dim3(64), 0, st, d);
     if (d.A == 64) hipLaunchKernelGGL((k_knn_finish<64>), g4, dim3(256), 0, st, d);
