@@ -269,19 +269,19 @@ struct gd_sim {
     }
 
     // Set-order road kernel: how the agents are dealt to workgroups and which of its two equivalent write-outs runs
-    // (map_obs.hip, launch_map_obs).  Neither changes a result.  Measured at 1024 x 64 (road observation, us):
-    //   full worlds (synthetic)   16 agents per wave + row kernel 315,  2 per wave + row kernel 306,  2 per wave + fused 322
-    //   ragged worlds (Waymo)     16 + row kernel 104,                   2 + row kernel 91,            2 + fused 81
-    //   4096 ragged worlds        16 + fused 278,                        2 + fused 293,                2 + row kernel 439
-    // so: many generations of workgroups -> big workgroups, rows stored by the selecting wave; otherwise small
-    // workgroups (a 64-agent world no longer holds its CU four times as long as a 15-agent one), fused when the batch is
-    // ragged.  GPUDRIVE_SET_FUSED_ROWS=0|1 and GPUDRIVE_SET_AGENTS_PER_WAVE=n pin them (the tests run the combinations).
+    // (map_obs.hip, launch_map_obs).  Neither changes a result.  Measured (road observation, us; tools/set_schedules.sh),
+    // agents per wave 1 / 2 / 4 / 16:
+    //   1024 full worlds (synthetic)   row kernel 183 / 181 / 180 / 192     fused 181 / 168 / 167 / 167
+    //   1024 ragged worlds (Waymo)     row kernel  83 /  80 /  82 /  84     fused  61 /  70 /  67 /  80
+    //   4096 ragged worlds             row kernel 411 / 399 / 392 / 392     fused 249 / 246 / 256 / 274
+    // Rounds 2 and 3 chose by batch shape (row kernel for full worlds, sixteen agents per wave for thousands of worlds):
+    // the selection then took twice the instructions it takes now (map_obs.hip), and rows stored by the selecting waves
+    // had little to hide behind.  Now: always fused, two agents per wave -- enough workgroups for every batch, and the
+    // second agent's inputs arrive while the first is selected.
+    // GPUDRIVE_SET_FUSED_ROWS=0|1 and GPUDRIVE_SET_AGENTS_PER_WAVE=n pin them (the tests run the combinations).
     void choose_set_schedule() {
-        bool ragged = false;
-        for (int w = 0; w < W; w++) ragged = ragged || w_agents[w] < A;
-        const bool many = W >= 8 * cu_count;
-        d.set_apw = many ? 16 : 2;
-        d.set_fused_rows = (many || ragged) ? 1 : 0;
+        d.set_apw = 2;
+        d.set_fused_rows = 1;
         if (const char *e = std::getenv("GPUDRIVE_SET_FUSED_ROWS")) d.set_fused_rows = std::atoi(e) != 0 ? 1 : 0;
         if (const char *e = std::getenv("GPUDRIVE_SET_AGENTS_PER_WAVE")) d.set_apw = std::min(32, std::max(1, std::atoi(e)));
     }

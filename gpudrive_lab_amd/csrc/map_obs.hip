@@ -1010,7 +1010,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
     float *ckey = s_ckey[wave];
     unsigned short *cidx = s_cidx[wave];
     unsigned int *bits = s_bits[wave];
-    const unsigned long long lower = (1ull << lane) - 1ull;
     const float2 *rxy = d.road_xy + r0;
     const GridHdr g = d.rgrid[w];
     const int32_t *coff = d.rcell_off + g.cell_base;
