@@ -10,7 +10,7 @@ import numpy as np, torch
 import bench
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 dev = torch.device("cuda", 0)
-for wl, W in (("synthetic", 1024), ("waymo", 1024), ("cfg3", 4096), ("waymo_raw", 1024)):
+for wl, W in (("synthetic", 1024), ("waymo", 1024), ("cfg3", 4096), ("waymo_raw", 1024), ("synthetic_set", 1024), ("waymo_set", 1024), ("cfg3_set", 4096)):
     name, order, agents = bench.split_workload(wl)
     t0 = time.time()
     with torch.cuda.stream(torch.cuda.Stream(device=dev)):
