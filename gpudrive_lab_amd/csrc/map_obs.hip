@@ -460,11 +460,20 @@ __device__ __forceinline__ void road_row(float *o, bool selected, bool knn, floa
     }
     const unsigned int bits = __float_as_uint(q1.w);
     const int type = (int)(bits & 0xffu), map_type = (int)(bits >> 8) - 1;
-    const Quat einv = quat_inv(quat_from_wz(ew, ez));
-    const V2 rel = ego_relative(ex, ey, einv, q0.x, q0.y);
+    // Every rotation here is a yaw rotation (x = y = +-0): the reference's rotateVec and Hamilton product with the terms
+    // that multiply those zeros dropped (gd_math.hpp rotate_yaw) -- a dropped term only ever adds a zero, so every non-zero
+    // result is the same float, and a zero result may differ in its sign, which matters in one place: the heading of a road
+    // exactly opposite to the agent (w z = 0: atan2f(+-0, negative) = +-pi, reference
+    // tests/EgocentricRoadObservationTests.cpp), so that case keeps the full product.  A row is 110 vector instructions
+    // with the general forms and 65 with these; the rows stored by the selecting waves (set order) are bound by exactly that.
+    const V2 rel = rotate_yaw(ew, -ez, q0.x - ex, q0.y - ey);
     o[0] = rel.x; o[1] = rel.y; o[2] = q1.x; o[3] = q1.y;
     o[4] = type == ET_StopSign ? 1.f : 0.1f;  // the z scale of the road entity (scene.cpp put_road)
-    o[5] = quat_to_yaw_row(quat_mul(einv, quat_from_wz(q0.z, q0.w)));
+    const float rw = q0.z, rz = q0.w, iz = -ez;
+    const float pw = ew * rw - iz * rz, pz = ew * rz + iz * rw;  // (w, z) of inverse(ego) * road
+    const float wz = pw * pz;
+    if (wz != 0.f) o[5] = atan2f(2.0f * wz, 1.0f - 2.0f * (pz * pz));
+    else o[5] = quat_to_yaw_row(quat_mul(quat_inv(quat_from_wz(ew, ez)), quat_from_wz(rw, rz)));
     o[6] = (float)type; o[7] = q1.z; o[8] = (float)map_type;
 }
 
@@ -994,6 +1003,7 @@ template <int A_T, int NW, bool FUSE>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_WPE))) void k_map_obs_set(DevSim d) {
     using S = SetSel<A_T>;
     constexpr int CAP = S::CAP, BMW = S::BMW;
+    constexpr int KR_MAX = 5;  // register slots of the K-th-key search: 64 candidates each
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int wg = d.set_groups[blockIdx.x];  // only groups of agent slots that hold a live agent are launched
     const int w = wg >> 8, tid = threadIdx.x;
@@ -1179,7 +1189,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
 #ifdef GD_CLOCKS
             clk_sum[7] += (unsigned int)nin;
 #endif
-            if (nin <= CAP) {
+            if (nin <= KR_MAX * 64) {  // (more: the full-stream path below -- a first selection with the radius for a bound, as a rule)
                 done = true;
                 reinterpret_cast<uint4 *>(bits)[lane] = make_uint4(0u, 0u, 0u, 0u);  // the histogram's words
                 wave_sync();
@@ -1188,10 +1198,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
                     count = min(nin, K);
                 } else {
                   // the K-th smallest key T: largest T with count(key < T) < K.  The candidates' key bits sit in
-                  // registers (lane l holds candidates l, l + 64, ...): KR slots.  Two instantiations of the block: five slots
-                  // (320 candidates -- the coherence bound leaves about 240 of them on the bench scene) and all CAP / 64;
-                  // every pass over the slots is unrolled with a guard per slot, and with sixteen slots for four used ones
-                  // the guards, the spilled scalars and the registers of the unused slots were a fifth of the kernel.
+                  // registers (lane l holds candidates l, l + 64, ...): five slots, 320 candidates -- the coherence bound
+                  // leaves about 240 of them on the bench scene.  (Rounds 2-4 also had a sixteen-slot instantiation for up to
+                  // CAP candidates: every pass over the slots is unrolled with a guard per slot, and its 141 registers cost
+                  // the kernel either a wave per SIMD or a dozen spilled registers on the path everybody takes: 164 -> 153 us
+                  // without it.  Agents with more candidates than the slots hold take the full-stream path.)
                   auto select = [&](auto slots_tag) {
                     constexpr int KR = decltype(slots_tag)::value;
                     unsigned int kb[KR];
@@ -1356,11 +1367,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
                     kth = __uint_as_float(lo);
                   };
 #if GD_SET_ABL == 3  // timing-only builds: the selection twice
-                  if (nin <= 5 * 64) select(std::integral_constant<int, 5>{});
+                  select(std::integral_constant<int, KR_MAX>{});
                   asm volatile("" ::: "memory");
 #endif
-                  if (nin <= 5 * 64) select(std::integral_constant<int, 5>{});
-                  else select(std::integral_constant<int, CAP / 64>{});
+                  select(std::integral_constant<int, KR_MAX>{});
                 }
                 wave_sync();
                 SET_PHASE(4);
