@@ -208,3 +208,49 @@ def test_rank_path_at_the_ends_of_its_arrays(oracle_mod, tmp_path, monkeypatch):
     assert path[0, 63] == 1272 and path[1, 63] == 1290
     assert gpu.stat(21) == 0
     gpu.close()
+
+
+# ---- road rows: headings of roads exactly along the axes of the agent's frame ----
+def _axis_scene(tmp_path, yaw):
+    """One parked vehicle at (100, 50) with the given yaw and four straight polylines through points around it: along +x, -x,
+    +y and -y of the WORLD frame, i.e. (for yaw a multiple of pi / 2) exactly aligned with, opposite to and perpendicular to
+    the agent's heading."""
+    def obj(i, x, y, yaw):
+        return {"position": [{"x": x, "y": y, "z": 0.0}] * 91, "width": 2.0, "length": 4.5, "height": 1.6, "heading": [yaw] * 91,
+                "velocity": [{"x": 0.0, "y": 0.0}] * 91, "valid": [True] * 91, "goalPosition": {"x": 400.0, "y": 400.0, "z": 0.0},
+                "type": "vehicle", "id": i, "mark_as_expert": False}
+    def line(rid, x0, y0, dx, dy):
+        return {"geometry": [{"x": x0 + dx * k, "y": y0 + dy * k, "z": 0.0} for k in range(6)], "type": "road_edge",
+                "map_element_id": 15, "id": rid}
+    sc = {"name": "axes", "scenario_id": "axes", "objects": [obj(0, 100.0, 50.0, yaw)],
+          "roads": [line(0, 104.0, 53.0, 2.0, 0.0), line(1, 96.0, 47.0, -2.0, 0.0), line(2, 103.0, 54.0, 0.0, 2.0),
+                    line(3, 97.0, 46.0, 0.0, -2.0)],
+          "tl_states": {}, "metadata": {"sdc_track_index": 0, "objects_of_interest": [], "tracks_to_predict": []}}
+    p = tmp_path / ("axes_%d.json" % round(yaw * 100))
+    p.write_text(json.dumps(sc))
+    return str(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knn_order", [0, 1], ids=["reference_order", "set_order"])
+def test_headings_of_roads_along_the_axes_of_the_agents_frame(oracle_mod, tmp_path, knn_order):
+    """`road_row` (map_obs.hip) uses the yaw-only forms of the reference's rotateVec and quaternion product, which can differ
+    from the general forms in the SIGN OF A ZERO only -- and a zero decides between +pi and -pi for a road exactly opposite to
+    the agent (atan2f(+-0, negative); reference tests/EgocentricRoadObservationTests.cpp pins +pi).  That case keeps the general
+    product; here: agents at yaw 0, pi / 2, pi, -pi / 2 with roads exactly along both axes in both directions, every row
+    against the oracle, headings within 1e-6 (so that +pi against -pi is a failure)."""
+    scenes = [_axis_scene(tmp_path, y) for y in (0.0, math.pi / 2, math.pi, -math.pi / 2)]
+    kw = dict(polylineReductionThreshold=0.0, observationRadius=50.0, collisionBehaviour=2, rewardType=1, distanceToGoalThreshold=2.0,
+              dynamicsModel=0, isStaticAgentControlled=1, initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
+    gpu = P.make_gpu_sim(scenes, max_agents=64, knn_order=knn_order, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    g = RC.as_np(gpu.agent_roadmap_tensor())[:, 0]
+    o = np.asarray(orc.agent_roadmap_tensor())[:, 0]
+    if knn_order == 1:
+        g, o = P._sorted_rows(g), P._sorted_rows(o)
+    live = o[:, :, 6] != 0
+    assert live.sum() >= 4 * 16, "the scenes' roads did not reach the observation"
+    assert np.abs(np.abs(o[live][:, 5]) - math.pi).min() < 1e-6, "no road exactly opposite to an agent: the scene does not exercise the case"
+    assert np.allclose(g[..., 5], o[..., 5], atol=1e-6, rtol=0), "headings differ (a sign of pi?)"
+    assert np.allclose(g, o, atol=P.OBS_ATOL, rtol=0)
+    gpu.close()
