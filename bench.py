@@ -89,13 +89,23 @@ WAYMO = [os.path.join(ROOT, "tests", "data", n) for n in
 def split_workload(name):
     """'synthetic_set' -> ('synthetic', 1, None): the same scenes with gd_config.knn_order = GD_KNN_SET_ORDER;
     'synthetic_128' -> ('synthetic', 0, 128): the same generator with the fork's own kMaxAgentCount = 128 agent slots
-    (reference src/consts.hpp:11), every one of them live."""
+    (reference src/consts.hpp:11), every one of them live.  A '_linear' suffix stays part of the workload's name
+    ('synthetic_linear', 'waymo_linear': the same scenes with roadObservationAlgorithm = AllEntitiesWithRadiusFiltering,
+    the `EnvConfig` default, reference gpudrive/env/config.py:51); 'ppo_default' is what the reference's PPO baselines run
+    (params_for) and always has the fork's 128 agent slots."""
     order, agents = 0, None
     if name.endswith("_set"):
         name, order = name[:-4], 1
     if name.endswith("_128"):
         name, agents = name[:-4], 128
+    if name == "ppo_default":
+        agents = 128
     return name, order, agents
+
+
+def scene_family(workload):
+    """'synthetic_linear' -> 'synthetic': which scenes a workload runs on."""
+    return workload[:-7] if workload.endswith("_linear") else workload
 
 
 def params_for(workload):
@@ -103,16 +113,24 @@ def params_for(workload):
               dynamicsModel=0, roadObservationAlgorithm=0, isStaticAgentControlled=1,
               initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
     # "waymo_raw": the Waymo tiles with unreduced polylines (5-10 thousand roads per world; not in the default list)
-    kw["polylineReductionThreshold"] = 0.0 if workload in ("synthetic", "rl_loop", "waymo_raw") else 0.1
+    kw["polylineReductionThreshold"] = 0.0 if scene_family(workload) in ("synthetic", "rl_loop", "waymo_raw") else 0.1
+    if workload.endswith("_linear") or workload == "ppo_default":
+        kw["roadObservationAlgorithm"] = 1  # AllEntitiesWithRadiusFiltering (reference src/sim.cpp:258-279)
     if workload == "lidar":  # BASELINE configs[4]: LiDAR 3 x 50 rays, mixed vehicle / cyclist / pedestrian agents
         kw["enableLidar"] = 1
     if workload == "cfg3":   # BASELINE configs[2]: 4 x the worlds, collisions stop agents, goal-reach reward
         kw["collisionBehaviour"] = 0
+    if workload == "ppo_default":
+        # what `baselines/ppo/ppo_pufferlib.py` with `baselines/ppo/config/ppo_base_puffer.yaml` constructs through an unchanged
+        # gpudrive/env/base_env.py:96-159: EnvConfig.road_obs_algorithm = "linear" (config.py:51), init_mode = "all_non_trivial"
+        # (config.py:137-139: parked cars stay Static, only agents valid at t = 0 exist), remove_non_vehicles = True,
+        # polyline_reduction_threshold 0.1, collision_behavior "ignore", dynamics "classic", kMaxAgentCount = 128
+        kw.update(isStaticAgentControlled=0, initOnlyValidAgentsAtFirstStep=1, IgnoreNonVehicles=1)
     return kw
 
 
 def scenes_for(workload, worlds, rank, agents=64):
-    if workload in ("synthetic", "rl_loop"):
+    if scene_family(workload) in ("synthetic", "rl_loop"):
         d = os.path.join(tempfile.gettempdir(), "gpudrive_amd_bench_scenes" + ("" if agents == 64 else "_%d" % agents))
         paths = synth.write_scenes(d, [rank * 1000 + i for i in range(8)], n_agents=agents)
         return [paths[i % len(paths)] for i in range(worlds)]
@@ -158,6 +176,33 @@ def run_steps(sim, batches, all_worlds, n, start=0, tracker=None):
     return start + n
 
 
+def linear_roads_scanned(sim, radius, k=200, chunk=16):
+    """Linear mode's algorithmic scan length, from the exported tensors of the state the run ended in (plain distances: a road
+    exactly at the radius may count either way): for every live agent the number of roads the reference's loop visits
+    (reference src/sim.cpp:261-275: up to and including the K-th road within the radius, or every road of the world).
+    Returns (sum over the live agents, sum over the worlds of the longest such prefix among the world's agents)."""
+    shape = sim.shape_tensor().to_torch()
+    pos = sim.absolute_self_observation_tensor().to_torch()[..., 0:2]
+    roads = sim.map_observation_tensor().to_torch()[..., 0:2]
+    W, A = pos.shape[0], pos.shape[1]
+    total, per_world = 0, 0
+    for w0 in range(0, W, chunk):
+        w1 = min(W, w0 + chunk)
+        n = shape[w0:w1, 0]
+        R = shape[w0:w1, 1]
+        rmax = int(R.max().item())
+        if rmax == 0:
+            continue
+        d2 = ((pos[w0:w1, :, None, :] - roads[w0:w1, None, :rmax, :]) ** 2).sum(-1)           # [w, A, rmax]
+        valid = torch.arange(rmax, device=d2.device)[None, None, :] < R[:, None, None]
+        reached = ((d2 <= radius * radius) & valid).cumsum(-1) >= k
+        first = torch.where(reached.any(-1), reached.int().argmax(-1) + 1, R[:, None].expand(-1, A).int())
+        live = torch.arange(A, device=d2.device)[None, :] < n[:, None]
+        total += int((first * live).sum().item())
+        per_world += int((first * live).max(dim=1).values.sum().item())
+    return total, per_world
+
+
 def bench_workload(workload, args, rank, local_rank, world, device):
     # everything (action writes, steps, resets) runs on one side stream: the engine replays its step as
     # a hipGraph there (the legacy null stream cannot be captured)
@@ -169,6 +214,7 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     workload, knn_order, agents_override = split_workload(name)
     knn_order = max(knn_order, args.knn_order)
     kw = params_for(workload)
+    linear = kw["roadObservationAlgorithm"] == 1
     if workload == "cfg3":
         args = argparse.Namespace(**dict(vars(args), worlds=4 * args.worlds))
     if agents_override:
@@ -243,8 +289,9 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     k = run_steps(sim, batches, all_worlds, 3, start=k, tracker=tracker)
     # the sums are zeroed after the spin-up and the alignment steps, right before the barrier and t0: `launches` == K
     # (+ the stretch's episode resets) and `kernels_sum_us` is comparable with `ms_per_step_events`
-    k, ev_elapsed = timed_stretch(k, pre_t0=lambda: sim.kernel_timing(True))
+    k, ev_elapsed = timed_stretch(k, pre_t0=lambda: (sim.kernel_timing(True), sim.stat(30)))  # (reading the skip counter zeroes it)
     ev_elapsed = sharding.reduce_max(ev_elapsed, device)
+    rows_skipped = sim.stat(30)  # agents whose road rows were left in place over the events stretch (pose bits unchanged)
     total_live = sharding.reduce_sum(live, device)
     res = dict(
         workload=name, seconds=elapsed, ms_per_step=1e3 * elapsed / args.steps,
@@ -258,7 +305,8 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         gc_ms_in_timed_stretches=gc_ms[0], spin_up_steps=spin_steps[0],
         worlds=args.worlds,
     )
-    names = {0: "k_world_step", 1: "k_map_obs+k_map_rows"}
+    road_kernel = "k_map_obs_linear" if linear else "k_map_obs+k_map_rows"
+    names = {0: "k_world_step", 1: road_kernel}
     if workload == "lidar":
         names[2] = "k_lidar"
     if workload == "bev":
@@ -280,7 +328,26 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     # every live agent's header (16 B) + K rows (7200 B) are written.  `traffic` (PMC) can be below the SURVEY figure
     # (its 36 B per road is not what this layout reads) but never below this one.
     design_min = float(sum(8.0 * int(r) + 32.0 * min(int(r), 200) + 7216.0 * int(n) for n, r in shape))
-    avg_s = kt["k_map_obs+k_map_rows"]["avg_us"] * 1e-6
+    survey_bytes = alg_bytes
+    scanned = None
+    if linear:
+        # linear mode: the reference's loop stops at the K-th road in reach, so the scan's algorithmic bytes are 8 B (x, y) per road
+        # VISITED, not SURVEY 8d's 36 B for every road of the world; the rows are the same 7216 B per live agent.  SURVEY's form
+        # rides along as `survey_bytes_per_launch`.
+        # Per WORLD, like SURVEY's form: a world's agents read the same roads, which HBM delivers once -- 8 B x the longest
+        # prefix any agent of the world visits.  (8 B x every agent's own prefix is what the L2 serves, not a byte count an HBM
+        # roofline can be priced against: 1.5 GB per step on the bench scene.)
+        scanned, scanned_world = linear_roads_scanned(sim, kw["observationRadius"])
+        alg_bytes = 8.0 * scanned_world + (16.0 + 7200.0) * live
+        design_min = alg_bytes
+    # Agents whose rows were left in place (pose bits unchanged since they were written: parked and finished agents) moved no
+    # bytes: they are taken out of the byte count that `achieved` / `frac` price, so that the fraction stays a statement about
+    # bytes the kernel moved; the reference's own count rides along as `reference_bytes_per_launch`.
+    launches = max(kt[road_kernel]["launches"], 1)
+    skipped_per_launch = rows_skipped / launches
+    reference_bytes = alg_bytes
+    alg_bytes -= 7216.0 * min(skipped_per_launch, live)
+    avg_s = kt[road_kernel]["avg_us"] * 1e-6
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     res["kernels"] = kt
     # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command
@@ -288,7 +355,9 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     # the source stamp of the build it was collected on; another build gets null.
     traffic = None
     try:
-        if workload in ("synthetic", "waymo"):
+        if linear:
+            tkey = workload
+        elif workload in ("synthetic", "waymo"):
             tkey = ("set_" if knn_order == 1 else "exact_") + workload
         else:  # lidar, bev, rl_loop: collected in the default (reference) row order only
             tkey = workload if knn_order == 0 else ("set_cfg3" if workload == "cfg3" else None)
@@ -304,10 +373,15 @@ def _bench_workload(name, args, rank, local_rank, world, device):
                 break
     except Exception:
         traffic = None
-    res["roofline"] = dict(bound="hbm", kernel="k_map_obs+k_map_rows", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+    res["roofline"] = dict(bound="hbm", kernel=road_kernel, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                            frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                           algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt["k_map_obs+k_map_rows"]["avg_us"],
+                           algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt[road_kernel]["avg_us"],
                            design_min_bytes_per_launch=design_min,
+                           survey_bytes_per_launch=survey_bytes, reference_bytes_per_launch=reference_bytes,
+                           roads_visited_until_k=scanned, agents_skipped_per_launch=skipped_per_launch,
+                           skip_note="an agent whose pose bits equal the ones its rows were last written for is not rewritten (parked / "
+                                     "finished agents); its 7216 B are NOT in algorithmic_bytes_per_launch; reference_bytes_per_launch "
+                                     "counts every live agent",
                            denominators="algorithmic_bytes_per_launch = SURVEY 8d's contract (36 R_w + 7216 N_w per world-step); "
                                         "design_min_bytes_per_launch = this layout's own floor (8 R_w scanned once per world + 32 B x "
                                         "min(R_w, K) gathered records + 7216 N_w written): traffic >= the second, not necessarily the first")
@@ -464,11 +538,14 @@ def main():
                     help="N > 1 only: after the timed region, a stretch with the observation all-gather of BASELINE configs[3] "
                          "(raw = every agent slot's packed observation, compact = controlled agents only), overlapped with the next step")
     ap.add_argument("--gather-steps", type=int, default=30)
-    ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop,synthetic_128,waymo_raw,synthetic_set,waymo_set,cfg3_set",
+    ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop,synthetic_128,waymo_raw,synthetic_set,waymo_set,cfg3_set,"
+                                            "synthetic_linear,waymo_linear,ppo_default",
                     help="first = primary; synthetic | waymo | cfg3 | lidar (Waymo tiles + 360-degree LiDAR) | bev | rl_loop | "
                          "waymo_raw (the Waymo tiles with unreduced polylines, the setting of the reference's C++ tests); "
                          "a _128 suffix = 128 agent slots per world (the fork's kMaxAgentCount), a _set suffix = the same scenes "
-                         "in set order (knn_order 1)")
+                         "in set order (knn_order 1), a _linear suffix = the same scenes with the linear road selection (the "
+                         "reference's EnvConfig default); ppo_default = what the reference's PPO baselines construct (Waymo tiles, "
+                         "128 agent slots, linear, init_mode all_non_trivial, vehicles only)")
     ap.add_argument("--spin-ms", type=float, default=200.0,
                     help="untimed steps for this many ms of wall clock before each timed stretch (device spin-up after the idle "
                          "world build; 0 = none)")

@@ -115,7 +115,8 @@ struct gd_sim {
     void *d_rcell_off = nullptr, *d_rcell_items = nullptr, *d_rcell_xy = nullptr;
     size_t cell_cap = 0, item_cap = 0;
     void *d_cell_off = nullptr, *d_cell_items = nullptr, *d_cell_hdr = nullptr;
-    size_t road_cap = 0, box_cap = 0;
+    size_t road_cap = 0, box_cap = 0, blk_cap = 0;
+    void *d_road_blk = nullptr;
     void *d_road_xy = nullptr, *d_road_aux = nullptr, *d_road_rec = nullptr, *d_boxes = nullptr;
     // pinned flag staging ring
     static constexpr int kRing = 8;
@@ -132,6 +133,7 @@ struct gd_sim {
     // inside the captured step graph
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    size_t lin_cap = 0;        // entries of d.lin_groups
     bool rk_possible = false;  // reference order, k-NN, not switched off: a batch may take the rank replay
     bool rk_alloc = false;     // its buffers exist
 
@@ -161,7 +163,6 @@ struct gd_sim {
             d.rk_ticket = alloc_internal<int32_t>(WA);
             d.rk_order = alloc_internal<int32_t>(WA);
             d.rk_list = alloc_internal<int32_t>(8 * WA);
-            d.road_bbox = alloc_internal<float4>(W);
             // the long list: room for a quarter of the agent slots (an agent beyond that takes the fallback)
             d.rk_nlong = static_cast<int>(std::max<size_t>(WA / 4, 64));
             d.rk_longlist = alloc_internal<int32_t>(d.rk_nlong);
@@ -200,6 +201,7 @@ struct gd_sim {
         if (d_road_aux) (void)hipFree(d_road_aux);
         if (d_road_rec) (void)hipFree(d_road_rec);
         if (d_boxes) (void)hipFree(d_boxes);
+        if (d_road_blk) (void)hipFree(d_road_blk);
         if (d_cell_off) (void)hipFree(d_cell_off);
         if (d_cell_items) (void)hipFree(d_cell_items);
         if (d_cell_hdr) (void)hipFree(d_cell_hdr);
@@ -218,8 +220,8 @@ struct gd_sim {
     T *alloc_internal(size_t count) {
         void *p = nullptr;
         HIP_CHECK(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+        internal.push_back(p);  // owned from here on: a failing memset must not leak it
         HIP_CHECK(hipMemset(p, 0, std::max<size_t>(count * sizeof(T), 16)));
-        internal.push_back(p);
         return static_cast<T *>(p);
     }
 
@@ -620,6 +622,53 @@ struct gd_sim {
         d.boxes = static_cast<const float4 *>(d_boxes);
         HIP_CHECK(hipMemcpy(d.rebuilt_flags, rebuilt.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice));
         choose_set_schedule();
+        {
+            // the box around every world's roads: an agent farther than the radius from it has no road in reach (linear scan,
+            // rank replay)
+            std::vector<float> bb(static_cast<size_t>(W) * 4);
+            for (int w = 0; w < W; w++) {
+                float lo_x = INFINITY, lo_y = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY;
+                for (size_t r = 0; r * 2 < w_xy[w].size(); r++) {
+                    lo_x = std::min(lo_x, w_xy[w][2 * r]); hi_x = std::max(hi_x, w_xy[w][2 * r]);
+                    lo_y = std::min(lo_y, w_xy[w][2 * r + 1]); hi_y = std::max(hi_y, w_xy[w][2 * r + 1]);
+                }
+                bb[w * 4 + 0] = lo_x; bb[w * 4 + 1] = lo_y; bb[w * 4 + 2] = hi_x; bb[w * 4 + 3] = hi_y;
+            }
+            HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
+            // the circle around every GD_LIN_BLK consecutive road points of a world (centre of their bounding box, the largest
+            // distance from it to one of them, rounded up)
+            std::vector<int32_t> boff(W + 1, 0);
+            for (int w = 0; w < W; w++) boff[w + 1] = boff[w] + static_cast<int32_t>((w_xy[w].size() / 2 + GD_LIN_BLK - 1) / GD_LIN_BLK);
+            std::vector<float> blk(static_cast<size_t>(boff[W]) * 4 + 4, 0.f);
+            for (int w = 0; w < W; w++) {
+                const std::vector<float> &xy = w_xy[w];
+                const size_t nr = xy.size() / 2;
+                for (size_t b = 0; b * GD_LIN_BLK < nr; b++) {
+                    const size_t r_lo = b * GD_LIN_BLK, r_hi = std::min(nr, r_lo + GD_LIN_BLK);
+                    float lo_x = INFINITY, lo_y = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY;
+                    for (size_t r = r_lo; r < r_hi; r++) {
+                        lo_x = std::min(lo_x, xy[2 * r]); hi_x = std::max(hi_x, xy[2 * r]);
+                        lo_y = std::min(lo_y, xy[2 * r + 1]); hi_y = std::max(hi_y, xy[2 * r + 1]);
+                    }
+                    const float cx = 0.5f * (lo_x + hi_x), cy = 0.5f * (lo_y + hi_y);
+                    float rad = 0.f;
+                    for (size_t r = r_lo; r < r_hi; r++)
+                        rad = std::max(rad, std::sqrt((xy[2 * r] - cx) * (xy[2 * r] - cx) + (xy[2 * r + 1] - cy) * (xy[2 * r + 1] - cy)));
+                    float *o = &blk[(static_cast<size_t>(boff[w]) + b) * 4];
+                    o[0] = cx; o[1] = cy; o[2] = rad * 1.0001f + 1e-3f; o[3] = 0.f;
+                }
+            }
+            if (blk.size() / 4 > blk_cap || !d_road_blk) {
+                if (d_road_blk) (void)hipFree(d_road_blk);
+                blk_cap = blk.size() / 4 + blk.size() / 32 + 64;
+                HIP_CHECK(hipMalloc(&d_road_blk, blk_cap * sizeof(float) * 4));
+            }
+            HIP_CHECK(hipMemcpy(d_road_blk, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(const_cast<int32_t *>(d.blk_off), boff.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice));
+            d.road_blk = static_cast<const float4 *>(d_road_blk);
+            // no row written before this call describes the worlds as they are now (roads, agent slots): every pose stamp dies
+            HIP_CHECK(hipMemsetAsync(d.pose_stamp, 0xff, sizeof(uint4) * static_cast<size_t>(W) * A, stream));
+        }
         if (rk_possible) {
             // Which worlds take the rank replay (neither path changes a result).  Measured at 64 agent slots (road
             // observation, ms): 1024 worlds x 4096 roads 1.19 ranked / 1.84 on keys; 1024 Waymo tiles (346-873 roads) 0.44 /
@@ -662,6 +711,30 @@ struct gd_sim {
                     if (g * per < w_agents[w]) groups.push_back(w << 8 | g);
             d.set_group_count = static_cast<int>(groups.size());
             if (!groups.empty()) HIP_CHECK(hipMemcpy(d.set_groups, groups.data(), sizeof(int32_t) * groups.size(), hipMemcpyHostToDevice));
+        }
+        {
+            // the linear scan's workgroups (4 waves x lin_apw agents each), world-major inside eight classes that are interleaved
+            // entry by entry: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, dispatch), so every workgroup of a world -- and the
+            // world's road arrays -- stays on one XCD's L2.  Classes are filled greedily (fewest workgroups so far) so that ragged
+            // batches leave few filler entries.
+            const int per = 4 * d.lin_apw;
+            std::vector<int32_t> seq[8];
+            for (int w = 0; w < W; w++) {
+                const int ng = (w_agents[w] + per - 1) / per;
+                if (ng == 0) continue;
+                int c = w % 8;
+                for (int k = 0; k < 8; k++)
+                    if (seq[k].size() + 4 * static_cast<size_t>(A / per) < seq[c].size()) c = k;  // only when a class runs far ahead
+                for (int g = 0; g < ng; g++) seq[c].push_back(w << 8 | g);
+            }
+            size_t len = 0;
+            for (auto &q : seq) len = std::max(len, q.size());
+            std::vector<int32_t> list(len * 8, -1);
+            for (int c = 0; c < 8; c++)
+                for (size_t j = 0; j < seq[c].size(); j++) list[j * 8 + c] = seq[c][j];
+            if (list.size() > lin_cap) throw std::runtime_error("linear-scan work list: more workgroups than the list holds");
+            d.lin_group_count = static_cast<int>(list.size());
+            if (!list.empty()) HIP_CHECK(hipMemcpy(d.lin_groups, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice));
         }
         launch(gd::KERNEL_PADDING, false);
     }
@@ -751,16 +824,6 @@ struct gd_sim {
     // every agent takes the fallback, which records fresh ones.
     void reset_rank_state() {
         HIP_CHECK(hipMemset(d.cp_hdr, 0, sizeof(float4) * 2 * static_cast<size_t>(W) * A));
-        std::vector<float> bb(static_cast<size_t>(W) * 4);
-        for (int w = 0; w < W; w++) {
-            float lo_x = INFINITY, lo_y = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY;
-            for (size_t r = 0; r * 2 < w_xy[w].size(); r++) {
-                lo_x = std::min(lo_x, w_xy[w][2 * r]); hi_x = std::max(hi_x, w_xy[w][2 * r]);
-                lo_y = std::min(lo_y, w_xy[w][2 * r + 1]); hi_y = std::max(hi_y, w_xy[w][2 * r + 1]);
-            }
-            bb[w * 4 + 0] = lo_x; bb[w * 4 + 1] = lo_y; bb[w * 4 + 2] = hi_x; bb[w * 4 + 3] = hi_y;
-        }
-        HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemset(d.rk_fallback, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
         HIP_CHECK(hipMemset(d.rk_streak, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));
         HIP_CHECK(hipMemset(d.rk_hist, 0, sizeof(int32_t) * GD_RANK_AUDIT));  // bin counts, the lists of ranked agents: empty (the audit counter behind them keeps counting)
@@ -960,6 +1023,18 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.grid = s->alloc_internal<gd::GridHdr>(W);
         d.rgrid = s->alloc_internal<gd::GridHdr>(W);
         d.knn_prev = s->alloc_internal<float4>(WA);
+        d.road_bbox = s->alloc_internal<float4>(W);
+        d.lin_apw = 2;
+        if (const char *e = std::getenv("GPUDRIVE_LIN_AGENTS_PER_WAVE")) d.lin_apw = std::min(A / 4, std::max(1, std::atoi(e)));
+        // worst case: every class as long as the longest one, which holds at most ceil(W / 8) + a few worlds' workgroups
+        s->lin_cap = (static_cast<size_t>(W) + 64) * static_cast<size_t>((A + 4 * d.lin_apw - 1) / (4 * d.lin_apw)) + 64;
+        d.lin_groups = s->alloc_internal<int32_t>(s->lin_cap);
+        d.lin_group_count = 0;
+        d.lin_on = std::getenv("GPUDRIVE_LINEAR_LEGACY") == nullptr ? 1 : 0;
+        d.pose_stamp = s->alloc_internal<uint4>(WA);
+        d.pose_skip = std::getenv("GPUDRIVE_NO_POSE_SKIP") == nullptr ? 1 : 0;
+        d.stat_skipped = s->alloc_internal<unsigned long long>(GD_SKIP_SLOTS);
+        d.blk_off = s->alloc_internal<int32_t>(W + 1);
         // rank replay of the reference-order selection (map_obs_rank.hip): a fallback group is one workgroup of k_map_obs.
         // Its buffers (7.4 KB per agent slot) are allocated when a batch first takes the path (rebuild_worlds).
         d.rk_on = 0;
@@ -1147,6 +1222,17 @@ int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
 #else
     constexpr int32_t kLastStat = 7;
 #endif
+    if (s && out && which == 30) {  // agents whose road rows were left in place (pose unchanged) since the last read
+        std::vector<unsigned long long> v(GD_SKIP_SLOTS, 0);
+        (void)hipStreamSynchronize(s->stream);
+        if (hipMemcpy(v.data(), s->d.stat_skipped, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemset(s->d.stat_skipped, 0, sizeof(unsigned long long) * v.size()) != hipSuccess)
+            return fail(GD_ERR_DEVICE, "gd_stat: reading the skip counters failed");
+        unsigned long long sum = 0;
+        for (unsigned long long x : v) sum += x;
+        *out = static_cast<int64_t>(sum);
+        return GD_OK;
+    }
     if (s && out && which == 21) {  // bounds audit of the rank path (engine.hpp GD_RANK_AUDIT): violations since the buffers exist
         *out = 0;
         if (s->rk_alloc) {

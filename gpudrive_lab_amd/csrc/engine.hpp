@@ -28,6 +28,8 @@
 // checked against its array before it is used; a violation is counted here and the index clamped into the array, so that
 // a broken invariant shows up as a failed test (gd_stat 21 must read 0), never as an access outside an allocation.
 #define GD_RANK_AUDIT 536
+#define GD_LIN_BLK 16       // roads per block of the linear scan's cull (map_obs_linear.hip)
+#define GD_SKIP_SLOTS 4096  // counters of DevSim::stat_skipped
 
 // Phase switches for timing experiments exist only in diagnostic builds (-DGD_DIAG); in the product library the
 // condition is the constant false and the compiler drops the code.
@@ -110,6 +112,24 @@ struct DevSim {
     const uint16_t *rcell_items;   // local road indices
     const float2 *rcell_xy;        // the (x, y) of those roads, in the same (cell-sorted) order: one coalesced stream per grid row
     float4 *knn_prev;              // [W][A] {x, y, K-th key of the previous selection or +inf, 0}
+    // linear road selection (map_obs_linear.hip): workgroups of 4 waves x lin_apw agent slots, (world << 8 | group) or -1 (filler),
+    // ordered so that every workgroup of a world has the same index modulo 8 (= runs on the same XCD)
+    int32_t *lin_groups;
+    int lin_group_count;
+    // ... and skip whole blocks of GD_LIN_BLK consecutive roads that cannot hold a road in reach: per block the circle around its
+    // roads' points, (cx, cy, radius, 0); the blocks of world w start at blk_off[w] (roads follow their polylines in index order,
+    // so a block is a short piece of one polyline as a rule)
+    const float4 *road_blk;
+    const int32_t *blk_off;        // [W + 1]
+    int lin_apw;
+    int lin_on;                    // 0: GPUDRIVE_LINEAR_LEGACY=1 -- the linear scan inside k_map_obs / k_map_obs_set (rounds 1-4), for A/B runs
+    // rows that cannot have changed are not rewritten: the pose bits (x, y, qw, qz) an agent's road rows were last written for;
+    // x = 0xffffffff: none (set for every agent whenever worlds are rebuilt -- roads or agent slots may have changed)
+    uint4 *pose_stamp;             // [W][A]
+    int pose_skip;                 // 0: GPUDRIVE_NO_POSE_SKIP=1 -- every live agent's rows are rewritten on every step
+    unsigned long long *stat_skipped;  // [GD_SKIP_SLOTS] agents whose rows were left in place since the counters were last read (gd_stat 30
+                                       // sums them): every wave adds to the slot of its own index -- one counter for all of them
+                                       // serialises ten thousand atomics at one memory channel (measured: 150 us per launch)
     // reference-order road selection, rank replay (map_obs_rank.hip); rk_on = 0: k_map_obs alone selects
     int split_partner;  // the partner rows are written by k_partner_rows (second stream) instead of k_world_step
     int step_dbg;  // -DGD_DIAG builds only (tools/build_expt.sh): k_world_step skips 1 = the road-box loop, 2 = the agent-agent
@@ -151,6 +171,7 @@ struct DevSim {
 void launch_kernel(const DevSim &d, hipStream_t st, int which, bool move);
 void launch_map_obs(const DevSim &d, hipStream_t st);  // map_obs.hip
 void launch_map_obs_rank(const DevSim &d, hipStream_t st);  // map_obs_rank.hip
+void launch_map_obs_linear(const DevSim &d, hipStream_t st);  // map_obs_linear.hip
 void launch_bev(const DevSim &d, hipStream_t st);      // bev_lidar.hip
 void launch_lidar(const DevSim &d, hipStream_t st);    // bev_lidar.hip
 void launch_pack_obs(const DevSim &d, hipStream_t st, float *out);  // pack_obs.hip

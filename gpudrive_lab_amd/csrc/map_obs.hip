@@ -36,6 +36,7 @@
 
 #include "engine.hpp"
 #include "gd_math.hpp"
+#include "map_rows.hpp"
 
 #ifdef GD_STAMPS
 // diagnostic build only (tools/stamps.sh): per-workgroup cycle counts of the phases of k_map_obs
@@ -63,18 +64,6 @@ constexpr int AW = GD_MAP_OBS_AW;  // agents (heap columns) per workgroup = per 
 constexpr int G = 64 / AW;         // lanes per agent: lane = sub * AW + column
 constexpr int SLOTS = K + 2;       // stored slots 1..K (the heap), K+1 and K+2 (sentinels); slot g is row g - 1
 static_assert(AW == 16 || AW == 32 || AW == 64, "agents per wave");
-
-// Intra-wave ordering point for LDS traffic between lanes of one wave.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Set bits of `b` below this lane's own (v_mbcnt_lo / v_mbcnt_hi: two instructions; popc(b & lower_mask) is four).
-__device__ __forceinline__ int bits_below_lane(unsigned long long b) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)b, 0u));
-}
 
 // Position of column `c` in a row of the u16 index array.  With 64 columns, c and c + 32 share a dword, so the
 // 32 lanes of either half of the wave (the LDS services them separately) touch 32 different banks.
@@ -448,34 +437,7 @@ __device__ __forceinline__ void drain_round(const Heap &heap, Heap::Top &top, Dr
 // One thread per (world, agent, slot) row of agent_roadmap_tensor; a wave writes 64 consecutive 36-byte rows.  The row is
 // ReferenceFrame::observationOf (src/utils.hpp:36-49) of the selected road, or the padding row.  Splitting it from the
 // selection lets the gather / atan2 / store work run at full occupancy instead of behind the LDS-bound selection waves.
-// One row of agent_roadmap_tensor into o[0..9): the selected road (its 32-byte record, engine.hpp road_rec) seen from the agent
-// at (ex, ey) with rotation (ew, ez), or the padding row.
-__device__ __forceinline__ void road_row(float *o, bool selected, bool knn, float ex, float ey, float ew, float ez, float4 q0, float4 q1) {
-    if (!selected) {
-        // k-NN pads with fillZeros (id 0, mapType 0: src/knn.hpp:19-28); the linear scan pads with
-        // MapObservation::zero() (id -1, mapType -1: src/sim.cpp:277-279)
-        const float pad = knn ? 0.f : -1.f;
-        o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = (float)ET_None; o[7] = pad; o[8] = pad;
-        return;
-    }
-    const unsigned int bits = __float_as_uint(q1.w);
-    const int type = (int)(bits & 0xffu), map_type = (int)(bits >> 8) - 1;
-    // Every rotation here is a yaw rotation (x = y = +-0): the reference's rotateVec and Hamilton product with the terms
-    // that multiply those zeros dropped (gd_math.hpp rotate_yaw) -- a dropped term only ever adds a zero, so every non-zero
-    // result is the same float, and a zero result may differ in its sign, which matters in one place: the heading of a road
-    // exactly opposite to the agent (w z = 0: atan2f(+-0, negative) = +-pi, reference
-    // tests/EgocentricRoadObservationTests.cpp), so that case keeps the full product.  A row is 110 vector instructions
-    // with the general forms and 65 with these; the rows stored by the selecting waves (set order) are bound by exactly that.
-    const V2 rel = rotate_yaw(ew, -ez, q0.x - ex, q0.y - ey);
-    o[0] = rel.x; o[1] = rel.y; o[2] = q1.x; o[3] = q1.y;
-    o[4] = type == ET_StopSign ? 1.f : 0.1f;  // the z scale of the road entity (scene.cpp put_road)
-    const float rw = q0.z, rz = q0.w, iz = -ez;
-    const float pw = ew * rw - iz * rz, pz = ew * rz + iz * rw;  // (w, z) of inverse(ego) * road
-    const float wz = pw * pz;
-    if (wz != 0.f) o[5] = atan2f(2.0f * wz, 1.0f - 2.0f * (pz * pz));
-    else o[5] = quat_to_yaw_row(quat_mul(quat_inv(quat_from_wz(ew, ez)), quat_from_wz(rw, rz)));
-    o[6] = (float)type; o[7] = q1.z; o[8] = (float)map_type;
-}
+// (road_row: map_rows.hpp)
 
 // Launch order of the next k_map_obs (see "launch order" further down): counting sort of its workgroups by the cycles they
 // took, costliest first, by ONE workgroup of NT threads; `lds` needs 513 words.
@@ -1432,6 +1394,11 @@ void set_clocks_read(unsigned long long *out) {  // and zero them
 #endif
 
 void launch_map_obs(const DevSim &d, hipStream_t st) {
+    // AllEntitiesWithRadiusFiltering: rows in road-index order whatever knn_order says -- a kernel of its own (map_obs_linear.hip)
+    if (d.p.roadObservationAlgorithm != GD_ROADS_K_NEAREST && d.lin_on) {
+        launch_map_obs_linear(d, st);
+        return;
+    }
     if (d.knn_order == GD_KNN_SET_ORDER) {
         if (d.set_group_count == 0) return;
         const dim3 grid(d.set_group_count);

@@ -1,0 +1,175 @@
+"""GPU suite, round 5: the linear road selection (`AllEntitiesWithRadiusFiltering`, the reference's `EnvConfig` default:
+gpudrive/env/config.py:51 -> src/sim.cpp:258-279) in its own kernel (csrc/map_obs_linear.hip) against the oracle on the
+scenes bench.py times and at BASELINE.json's full size, against the kernels that carried the mode in rounds 1-4, and the rule
+that rows which cannot have changed are not rewritten (pose stamps) through resets, map changes and agent deletions.
+Everything goes through `madrona_gpudrive` -> ctypes -> the C ABI."""
+import numpy as np
+import pytest
+
+from gpudrive_lab_amd import synth
+from tests import parity as P
+from tests import ref_cases as RC
+from tests.conftest import SCENE_4, SCENE_407, TEST_JSON
+from tests.test_gpu_round3 import _Worlds, _tiled
+
+pytestmark = pytest.mark.gpu
+
+ALL_OBJECTS = dict(isStaticAgentControlled=1, initOnlyValidAgentsAtFirstStep=0, IgnoreNonVehicles=0)
+BENCH_LINEAR = dict(observationRadius=50.0, collisionBehaviour=2, rewardType=1, distanceToGoalThreshold=2.0, dynamicsModel=0,
+                    roadObservationAlgorithm=1, polylineReductionThreshold=0.0, **ALL_OBJECTS)
+WAYMO_LINEAR = dict(BENCH_LINEAR, polylineReductionThreshold=0.1)
+# what an unchanged gpudrive/env/base_env.py:96-159 builds from the EnvConfig defaults + baselines/ppo/config/ppo_base_puffer.yaml
+PPO_DEFAULT = dict(observationRadius=50.0, collisionBehaviour=2, rewardType=1, distanceToGoalThreshold=2.0, dynamicsModel=0,
+                   roadObservationAlgorithm=1, polylineReductionThreshold=0.1, isStaticAgentControlled=0,
+                   initOnlyValidAgentsAtFirstStep=1, IgnoreNonVehicles=1)
+
+
+@pytest.fixture(scope="module")
+def bench_scenes(tmp_path_factory):
+    return synth.write_scenes(str(tmp_path_factory.mktemp("bench_scenes5")), list(range(8)))
+
+
+def _bits(t):
+    return RC.as_np(t).view(np.uint32)
+
+
+def test_linear_mode_on_the_bench_scenes_in_lockstep_with_the_oracle(oracle_mod, bench_scenes):
+    """Two of the worlds bench.py's `synthetic_linear` times (64 live agents, 4096 road edges): t = 0, then a third of an
+    episode in lockstep -- rows elementwise (index order IS the mode's order), ints exact."""
+    scenes = bench_scenes[:2]
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **BENCH_LINEAR)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **BENCH_LINEAR)
+    P.compare_fresh(gpu, orc)
+    P.lockstep(gpu, orc, 30, 0, seed=11)
+    rows = RC.as_np(gpu.agent_roadmap_tensor())
+    assert (rows[..., 6] > 0).sum(-1).max() == 200, "some agent should fill all K rows on this scene (the early exit)"
+    gpu.close()
+
+
+@pytest.mark.parametrize("slots", [64, 128])
+def test_linear_mode_full_size_first_and_last_worlds_equal_the_oracle(oracle_mod, slots):
+    """1024 Waymo tiles (what `waymo_linear` / `ppo_default` run on): worlds 0-2 and the last three against the oracle,
+    every replica bit-identical to its scene's first world."""
+    import torch
+    W = 1024
+    kw = WAYMO_LINEAR if slots == 64 else PPO_DEFAULT
+    gpu = P.make_gpu_sim(_tiled(W), max_agents=slots, **kw)
+    orc = P.make_oracle_sim(oracle_mod, _tiled(3), max_agents=slots, **kw)
+    rng = np.random.default_rng(4)
+    last = [W - 3, W - 2, W - 1]
+    views = [(_Worlds(gpu, [0, 1, 2]), [0, 1, 2]), (_Worlds(gpu, last), [w % 3 for w in last])]
+    for step in range(9):
+        act3 = P.random_actions(rng, 3, slots, 0)
+        a = gpu.action_tensor().to_torch()
+        a.copy_(torch.as_tensor(act3).repeat((W + 2) // 3, 1, 1)[:W].to(a.device))
+        np.copyto(orc.action_tensor(), act3)
+        gpu.step()
+        orc.step()
+        for view, scene in views:
+            P.compare_ints(view, _Worlds(orc, scene), ["done_tensor", "info_tensor", "steps_remaining_tensor"])
+        if step % 4 == 0:
+            gpu.debug_set_state(np.tile(orc.get_state(), ((W + 2) // 3, 1, 1))[:W])
+            gpu.reset([])
+            orc.reset([])
+            for view, scene in views:
+                sub = _Worlds(orc, scene)
+                sub.W, sub.A = 3, slots
+                P.compare_obs(view, sub)
+    flat = gpu.agent_roadmap_tensor().to_torch().reshape(W, -1)
+    for r in range(3):
+        grp = flat[r::3]
+        assert torch.equal(grp, grp[0:1].expand_as(grp)), "agent_roadmap_tensor: replicas of scene %d diverged" % r
+    gpu.close()
+
+
+@pytest.mark.parametrize("which", ["bench", "waymo_128", "ppo_default"])
+def test_linear_kernel_equals_the_kernels_that_carried_the_mode_before(bench_scenes, monkeypatch, which):
+    """Free running, same scenes and actions: the linear kernel (with and without the pose stamps) against
+    GPUDRIVE_LINEAR_LEGACY=1 (the linear branch of k_map_obs + k_map_rows, rounds 1-4).  Bit-identical rows at every step,
+    through a reset of some worlds and a teleport of a few agents."""
+    if which == "bench":
+        scenes, kw, slots = bench_scenes[:3], BENCH_LINEAR, 64
+    elif which == "waymo_128":
+        scenes, kw, slots = [TEST_JSON, SCENE_407, SCENE_4], WAYMO_LINEAR, 128
+    else:
+        scenes, kw, slots = [TEST_JSON, SCENE_407, SCENE_4, SCENE_407], PPO_DEFAULT, 128
+    new = P.make_gpu_sim(scenes, max_agents=slots, **kw)
+    monkeypatch.setenv("GPUDRIVE_NO_POSE_SKIP", "1")
+    noskip = P.make_gpu_sim(scenes, max_agents=slots, **kw)
+    monkeypatch.delenv("GPUDRIVE_NO_POSE_SKIP")
+    monkeypatch.setenv("GPUDRIVE_LINEAR_LEGACY", "1")
+    old = P.make_gpu_sim(scenes, max_agents=slots, **kw)
+    monkeypatch.delenv("GPUDRIVE_LINEAR_LEGACY")
+    sims = [new, noskip, old]
+    W = len(scenes)
+    rng = np.random.default_rng(8)
+    new.stat(30)
+    for step in range(40):
+        act = P.random_actions(rng, W, slots, 0)
+        for s in sims:
+            RC.write_actions(s, act)
+            s.step()
+        if step == 12:
+            for s in sims:
+                s.reset([1])
+        if step == 20:  # a few agents 30 m away and turned: nothing about their previous rows holds
+            st = new.debug_get_state()
+            st[:, :3, 0] += 30.0
+            st[:, :3, 3], st[:, :3, 6] = np.cos(0.4), np.sin(0.4)
+            for s in sims:
+                s.debug_set_state(st)
+                s.reset([])
+        ref = _bits(old.agent_roadmap_tensor())
+        assert np.array_equal(_bits(new.agent_roadmap_tensor()), ref), "step %d: linear kernel differs from the legacy path" % step
+        assert np.array_equal(_bits(noskip.agent_roadmap_tensor()), ref), "step %d: (no pose skip) differs from the legacy path" % step
+    skipped = new.stat(30)
+    assert noskip.stat(30) == 0
+    if which == "ppo_default":
+        assert skipped > 0, "parked cars never move: their rows must have been left in place"
+    for s in sims:
+        s.close()
+
+
+def test_pose_stamps_die_with_the_world(oracle_mod, tmp_path):
+    """`ppo_default`-style worlds (parked cars stay Static) in lockstep with the oracle for a whole episode and into the next,
+    with a reset, a set_maps to other scenes (same poses may meet other roads), a set_maps back and a deleteAgents in the
+    middle.  Before every rebuild the road rows are overwritten with garbage from outside: rows that survive are rows the
+    engine skipped although the world changed."""
+    import torch
+    scenes = [TEST_JSON, SCENE_407, SCENE_4]
+    gpu = P.make_gpu_sim(scenes, max_agents=128, **PPO_DEFAULT)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=128, **PPO_DEFAULT)
+    P.compare_fresh(gpu, orc)
+    resp = np.asarray(orc.response_type_tensor())[..., 0]
+    live = P._live_mask(orc)
+    assert ((resp == 2) & live).sum() > 0, "the scenes should hold parked (Static) agents"
+    gpu.stat(30)
+    P.lockstep(gpu, orc, 40, 0, seed=2)
+    assert gpu.stat(30) > 0, "parked agents' rows should have been left in place"
+    gpu.reset([0, 2])
+    orc.reset([0, 2])
+    P.compare_obs(gpu, orc, atol=P.FREE_OBS_ATOL)
+    P.lockstep(gpu, orc, 10, 0, seed=3)
+    def scribble(value):
+        # (only the rows of live agents: padding agents' rows are written when their world is built, like in the reference,
+        # src/level_gen.cpp:308-336, and deleteAgents rebuilds only the worlds it names)
+        rows = gpu.agent_roadmap_tensor().to_torch()
+        n = gpu.shape_tensor().to_torch()[:, 0]
+        mask = torch.arange(rows.shape[1], device=rows.device)[None, :] < n[:, None]
+        rows[mask] = value
+
+    for new_scenes in ([SCENE_4, TEST_JSON, SCENE_407], scenes):
+        scribble(123.0)
+        gpu.set_maps(new_scenes)
+        orc.set_maps(new_scenes)
+        P.compare_fresh(gpu, orc)
+        P.lockstep(gpu, orc, 6, 0, seed=4)
+    scribble(-7.0)
+    ids = np.asarray(orc.agent_id_tensor())
+    victims = {1: [int(ids[1, 0]), int(ids[1, 2])], 2: [int(ids[2, 1])]}
+    gpu.deleteAgents(victims)
+    orc.deleteAgents(victims)
+    P.compare_fresh(gpu, orc)
+    P.lockstep(gpu, orc, 60, 0, seed=5)   # through the episode's end: finished agents are parked at the padding position
+    torch.cuda.synchronize()
+    gpu.close()
