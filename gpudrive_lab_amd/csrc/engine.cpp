@@ -19,7 +19,7 @@
 #include "gd_math.hpp"
 #include "scene.hpp"
 #ifdef GD_CLOCKS
-namespace gd { void set_clocks_read(unsigned long long *out); }
+namespace gd { void set_clocks_read(unsigned long long *out); void step_clocks_read(unsigned long long *out); }
 #endif
 #ifndef GD_GRID_MIN_CELL
 #define GD_GRID_MIN_CELL 16.f
@@ -588,7 +588,10 @@ struct gd_sim {
                     for (size_t i = 0; i < items.size(); i++) {
                         const gd::RoadBox &b = w_boxes[w][items[i]];
                         float *o = &ch[(static_cast<size_t>(w_grid[w].item_base) + i) * 4];
-                        o[0] = b.cx; o[1] = b.cy; o[2] = b.radius; o[3] = b.type;
+                        // (centre, bounding radius, entity type | local box index << 8): what the cull needs and where the box is
+                        const uint32_t packed = (static_cast<uint32_t>(static_cast<int>(b.type)) & 0xffu) | (static_cast<uint32_t>(items[i]) << 8);
+                        o[0] = b.cx; o[1] = b.cy; o[2] = b.radius;
+                        std::memcpy(&o[3], &packed, sizeof(packed));
                     }
                 }
                 if (nitem) HIP_CHECK(hipMemcpy(d_cell_hdr, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1214,6 +1217,14 @@ int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
         static unsigned long long clk[8];
         if (which == 22) gd::set_clocks_read(clk);
         *out = (int64_t)clk[which - 22];
+        return GD_OK;
+    }
+#endif
+#ifdef GD_CLOCKS
+    if (s && out && which >= 32 && which <= 43) {  // k_world_step's phase clocks and counters (kernels.hip g_step_clk / g_step_cnt): 32 reads and zeroes all
+        static unsigned long long clk[12];
+        if (which == 32) gd::step_clocks_read(clk);
+        *out = (int64_t)clk[which - 32];
         return GD_OK;
     }
 #endif

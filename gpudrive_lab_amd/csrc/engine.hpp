@@ -104,7 +104,7 @@ struct DevSim {
     const GridHdr *grid;        // [W]
     const int32_t *cell_off;    // per world nx*ny+1 entries, local offsets
     const int32_t *cell_items;  // local box indices
-    const float4 *cell_hdr;     // (cx, cy, bounding radius, type) of those boxes, in the same cell order: the cull reads them as a stream
+    const float4 *cell_hdr;     // (cx, cy, bounding radius, bits: type | local box index << 8) of those boxes, in the same cell order
     // set-order road selection: per-world uniform grid over ALL roads (a road sits in the cell of its (x, y)), CSR of
     // local road indices ascending within a cell, and per agent where and how far the previous selection reached
     const GridHdr *rgrid;          // [W]

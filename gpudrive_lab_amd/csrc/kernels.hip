@@ -38,17 +38,19 @@ __device__ __forceinline__ void forward_classic(const float *act, float length, 
     const float v = fmaxf(fminf(speed + 0.5f * act[0] * dt, maxSpeed), -maxSpeed);
     const float tanDelta = p_tan(act[1]);
     const float beta = p_atan(0.5f * tanDelta);
-    const float dx = v * p_cos(yaw + beta), dy = v * p_sin(yaw + beta);
+    float sn, cs;
+    p_sincos(yaw + beta, sn, cs);
+    const float dx = v * cs, dy = v * sn;
     const float w = v * p_cos(beta) * tanDelta / length;
     const float new_yaw = angle_add(yaw, w * dt);
     const float new_speed = fmaxf(fminf(speed + act[0] * dt, maxSpeed), -maxSpeed);
     b.px += dx * dt;
     b.py += dy * dt;
     b.pz = 1.f;
-    b.qw = p_cos(new_yaw / 2.f);
-    b.qz = p_sin(new_yaw / 2.f);
-    b.vx = new_speed * p_cos(new_yaw);
-    b.vy = new_speed * p_sin(new_yaw);
+    p_sincos(new_yaw / 2.f, b.qz, b.qw);
+    p_sincos(new_yaw, sn, cs);
+    b.vx = new_speed * cs;
+    b.vy = new_speed * sn;
     b.vz = 0.f;
 }
 
@@ -58,22 +60,25 @@ __device__ __forceinline__ void forward_bicycle(float *act, Body &b) {  // :52-8
     const float dt = 0.1f;
     const float yaw = quat_to_yaw(quat_from_wz(b.qw, b.qz));
     const float speed = len_3(b.vx, b.vy, b.vz);
-    b.px = (float)((double)(b.px + b.vx * dt) + 0.5 * act[0] * p_cos(yaw) * dt * dt);
-    b.py = (float)((double)(b.py + b.vy * dt) + 0.5 * act[0] * p_sin(yaw) * dt * dt);
+    float sn, cs;
+    p_sincos(yaw, sn, cs);
+    b.px = (float)((double)(b.px + b.vx * dt) + 0.5 * act[0] * cs * dt * dt);
+    b.py = (float)((double)(b.py + b.vy * dt) + 0.5 * act[0] * sn * dt * dt);
     const float delta_yaw = (float)(act[1] * ((double)(speed * dt) + 0.5 * act[0] * dt * dt));
     const float new_yaw = angle_add(yaw, delta_yaw);
     const float new_speed = speed + act[0] * dt;
-    b.vx = new_speed * p_cos(new_yaw);
-    b.vy = new_speed * p_sin(new_yaw);
+    p_sincos(new_yaw, sn, cs);
+    b.vx = new_speed * cs;
+    b.vy = new_speed * sn;
     b.vz = 0.f;
-    b.qw = p_cos(new_yaw / 2.f);
-    b.qz = p_sin(new_yaw / 2.f);
+    p_sincos(new_yaw / 2.f, b.qz, b.qw);
 }
 
 __device__ __forceinline__ void forward_delta(const float *act, Body &b) {  // :83-115
     const float dt = 0.1f;
     const float yaw = quat_to_yaw(quat_from_wz(b.qw, b.qz));
-    const float c = p_cos(yaw), s = p_sin(yaw);
+    float c, s;
+    p_sincos(yaw, s, c);
     const float dx = act[0] * c - act[1] * s;
     const float dy = act[0] * s + act[1] * c;
     b.px = b.px + dx;
@@ -82,15 +87,13 @@ __device__ __forceinline__ void forward_delta(const float *act, Body &b) {  // :
     b.vy = dy / dt;
     b.vz = 0.f;
     const float new_yaw = angle_add(yaw, act[2]);
-    b.qw = p_cos(new_yaw / 2.f);
-    b.qz = p_sin(new_yaw / 2.f);
+    p_sincos(new_yaw / 2.f, b.qz, b.qw);
 }
 
 __device__ __forceinline__ void forward_state(const float *act, Body &b) {  // :186-194
     b.px = act[0]; b.py = act[1]; b.pz = act[2];
     b.vx = act[4]; b.vy = act[5]; b.vz = act[6];
-    b.qw = p_cos(act[3] / 2.f);
-    b.qz = p_sin(act[3] / 2.f);
+    p_sincos(act[3] / 2.f, b.qz, b.qw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,6 +183,17 @@ __global__ __launch_bounds__(A_T) void k_init_padding_rows(DevSim d) {
 // ------------------------------------------------------------------------------------------
 constexpr int STEP_THREADS = 256;  // agents live on threads [0, A); all threads write partner rows
 
+#ifdef GD_CLOCKS
+// -DGD_CLOCKS builds (tools/build_expt.sh clk -DGD_CLOCKS; tools/step_clocks.py): s_memtime ticks per phase of k_world_step as seen by
+// thread 0 of every workgroup, summed (gd_stat 32..39): 0 loads, 1 movement, 2 publish + OBB, 3 agent pairs, 4 road boxes,
+// 5 flags + reward / done + write-back + self / absolute rows, 6 partner rows, 7 = workgroups
+__device__ unsigned long long g_step_clk[8];
+__device__ unsigned long long g_step_cnt[4];  // road-box items, items that pass the cull, hits (read with the clocks: gd_stat 40..42)
+#define STEP_PHASE(n) do { if (a == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_step_clk[n], t_ - clk_prev); clk_prev = t_; } } while (0)
+#else
+#define STEP_PHASE(n) do {} while (0)
+#endif
+
 // collectPartnerObsSystem, src/sim.cpp:188-240, for one world by STEP_THREADS threads.  One thread per (ego, slot) row; a chunk
 // of STEP_THREADS consecutive 36-byte rows is assembled in LDS (row stride 9 floats: conflict-free) and leaves as whole
 // 16-byte pieces with streaming stores (a world's block starts at a multiple of 16 bytes and so does every chunk; only the
@@ -203,12 +217,21 @@ __device__ __forceinline__ void partner_rows(const DevSim &d, int w, int n, int 
                     o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -2.f;
                 } else {
                     const int j = k < ego ? k : k + 1;  // OtherAgents order, src/level_gen.cpp:450-464
-                    const Quat ego_inv = quat_inv(quat_from_wz(s_qw[ego], s_qz[ego]));
-                    const V3 r = quat_rotate(ego_inv, V3{s_px[j] - s_px[ego], s_py[j] - s_py[ego], 0.f});
-                    if (len_2(r.x, r.y) > d.p.observationRadius) {  // zero(): id -1
+                    // Every rotation is a yaw rotation: rotateVec and the Hamilton product with the terms that multiply the zero x / y
+                    // components dropped (gd_math.hpp rotate_yaw; map_rows.hpp road_row has the argument: every non-zero result is the
+                    // same float, a zero may change its sign, which only the heading of an exactly opposite partner can see -- that
+                    // case keeps the full product).  `length() > radius` on the squared length (engine.cpp radius_key_max).
+                    const float ew = s_qw[ego], ez = s_qz[ego];
+                    const V2 r = rotate_yaw(ew, -ez, s_px[j] - s_px[ego], s_py[j] - s_py[ego]);
+                    if (r.x * r.x + r.y * r.y > d.radius_key_max) {  // zero(): id -1
                         o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -1.f;
                     } else {
-                        const float heading = quat_to_yaw_row(quat_mul(ego_inv, quat_from_wz(s_qw[j], s_qz[j])));
+                        const float rw = s_qw[j], rz = s_qz[j], iz = -ez;
+                        const float pw = ew * rw - iz * rz, pz = ew * rz + iz * rw;  // (w, z) of inverse(ego) * other
+                        const float wz = pw * pz;
+                        float heading;
+                        if (wz != 0.f) heading = atan2f(2.0f * wz, 1.0f - 2.0f * (pz * pz));
+                        else heading = quat_to_yaw_row(quat_mul(quat_inv(quat_from_wz(ew, ez)), quat_from_wz(rw, rz)));
                         o[0] = s_speed[j];
                         o[1] = r.x; o[2] = r.y;
                         o[3] = heading;
@@ -241,20 +264,31 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     const int n = d.shape[w * 2 + 0];
     const size_t i = (size_t)w * A_T + a;
     const bool live = a < n;
+    const GridHdr gh = d.grid[w];  // (uniform: requested with the first loads, long before the collision phase needs it)
+    const int bbase = d.box_off[w];
 
     __shared__ float s_px[A_T], s_py[A_T], s_qw[A_T], s_qz[A_T], s_speed[A_T];
     __shared__ float s_len[A_T], s_wid[A_T], s_hgt[A_T], s_rad[A_T];
     __shared__ int s_etype[A_T], s_id[A_T], s_flags[A_T];  // flags: bit0 active, bit1 static
     __shared__ float s_obb[14][A_T];
     __shared__ int s_hit[A_T];  // collision flags found by the threads sharing an agent
+    constexpr int SVCAP = 6 * STEP_THREADS;  // candidates looked at per trip of the road-box phase (six per thread)
+    __shared__ unsigned int s_sv[SVCAP];  // road boxes that passed the cull: agent | local box index << 8 | entity type << 28
+    __shared__ int s_nsv[2];
+    __shared__ int s_c0[A_T], s_coff[A_T], s_wtot[A_T / 64];  // road-box candidates: first entry, offset in the world's item list, per-wave totals
 
+#ifdef GD_CLOCKS
+    unsigned long long clk_prev = __builtin_amdgcn_s_memtime();
+    if (a == 0) atomicAdd(&g_step_clk[7], 1ull);
+#endif
     Body b{};
     int collided = 0, done = 0, resp = RESP_Static, controlled = 0, etype = 0;
     uint32_t steps = 0;
     int32_t info0 = 0, info1 = 0, info2 = 0, info3 = 0;
     float sc0 = 0.f, sc1 = 0.f, length = 0.f, width = 0.f, height = 0.f, gx = 0.f, gy = 0.f;
 
-    if (live) {
+    // (every agent slot of the world is readable: the loads do not wait for the world's agent count)
+    if (a < A_T) {
         b.px = d.px[i]; b.py = d.py[i]; b.pz = d.pz[i];
         b.qw = d.qw[i]; b.qz = d.qz[i];
         b.vx = d.vx[i]; b.vy = d.vy[i]; b.vz = d.vz[i];
@@ -271,6 +305,10 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         gx = d.goal_x[i]; gy = d.goal_y[i];
     }
 
+#ifdef GD_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STEP_PHASE(0);
     // ---- movementSystem, src/sim.cpp:294-383 ----
     if (MOVE && live) {
         if (collided) {
@@ -311,16 +349,18 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
                 b.px = t[2 * k]; b.py = t[2 * k + 1]; b.pz = 1.f;
                 b.vx = t[2 * 91 + 2 * k]; b.vy = t[2 * 91 + 2 * k + 1]; b.vz = 0.f;
                 const float heading = t[4 * 91 + k];
-                b.qw = p_cos(heading / 2.f);
-                b.qz = p_sin(heading / 2.f);
+                p_sincos(heading / 2.f, b.qz, b.qw);
             }
         }
     }
 
+    STEP_PHASE(1);
     // ---- publish per-agent geometry for the pair phases ----
     bool active = false;
+    float theta = 0.f;  // quat_to_yaw of the pose after the movement: the agent's box and its absolute row both need it
     if (a < A_T) s_hit[a] = 0;
     if (live) {
+        theta = quat_to_yaw(quat_from_wz(b.qw, b.qz));
         // isInvalidExpertOrDone, src/sim.cpp:631-662; agents parked at kPaddingPosition overlap nothing
         bool invalid;
         if (!controlled) {
@@ -338,13 +378,14 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         s_rad[a] = sqrtf(sc0 * sc0 + sc1 * sc1);
         s_flags[a] = (active ? 1 : 0) | (resp == RESP_Static ? 2 : 0);
         if (active) {
-            const Obb o = obb_from(b.px, b.py, quat_from_wz(b.qw, b.qz), sc0, sc1);
+            const Obb o = obb_from_yaw(b.px, b.py, theta, sc0, sc1);
             const float *of = reinterpret_cast<const float *>(&o);
 #pragma unroll
             for (int k = 0; k < 14; k++) s_obb[k][a] = of[k];
         }
     }
     __syncthreads();
+    STEP_PHASE(2);
 
     // ---- collisionDetectionSystem over broadphase candidates, src/sim.cpp:628-747, 792-801 ----
     // All STEP_THREADS threads work here: P = STEP_THREADS / A threads per agent share its candidate
@@ -385,48 +426,111 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
                 else if (otype == ET_Vehicle) hit |= 4;
                 else if (otype <= ET_Cyclist) hit |= 8;
             }
-            if (!me_static && !GD_DIAG_IS(d.step_dbg, 1)) {
-                // road boxes of the broadphase cell under the agent's centre
-                const GridHdr gh = d.grid[w];
-                const float fx = (mx - gh.ox) * gh.inv_cell, fy = (my - gh.oy) * gh.inv_cell;
-                if (gh.nx > 0 && fx >= 0.f && fy >= 0.f && fx < (float)gh.nx && fy < (float)gh.ny) {
-                    const int cell = (int)fy * gh.nx + (int)fx;
-                    const int c0 = d.cell_off[gh.cell_base + cell], c1 = d.cell_off[gh.cell_base + cell + 1];
-                    const int bbase = d.box_off[w];
-                    // the cull reads (centre, radius, type) from the cell-ordered copy, one candidate ahead; only a box that
-                    // passes it is fetched through its index
-                    const float4 *chdr = d.cell_hdr + gh.item_base;
-                    const int32_t *citem = d.cell_items + gh.item_base;
-                    int c = c0 + part;
-                    float4 hdr_n = make_float4(0.f, 0.f, 0.f, 0.f);
-                    int item_n = 0;
-                    if (c < c1) { hdr_n = chdr[c]; item_n = citem[c]; }
-                    for (; c < c1; c += P) {
-                        const float4 hdr = hdr_n;
-                        const size_t r = (size_t)(bbase + item_n);
-                        if (c + P < c1) { hdr_n = chdr[c + P]; item_n = citem[c + P]; }
-                        const int rtype = (int)hdr.w;
-                        if (collision_pair_filtered(my_type, rtype)) continue;
-                        const float dx = mx - hdr.x, dy = my - hdr.y;
-                        const float rr = (my_rad + hdr.z) * 1.001f + 0.01f;
-                        if (dx * dx + dy * dy > rr * rr) continue;
-                        const float4 q1 = d.boxes[r * 5 + 1], q2 = d.boxes[r * 5 + 2], q3 = d.boxes[r * 5 + 3],
-                                     q4 = d.boxes[r * 5 + 4];
-                        const float tmp[16] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,
-                                               q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
-                        Obb ro;
-                        float *of = reinterpret_cast<float *>(&ro);
-#pragma unroll
-                        for (int k = 0; k < 14; k++) of[k] = tmp[k];
-                        if (!obb_collided(me, ro)) continue;
-                        hit |= 1;
-                        if (rtype > ET_None && rtype <= ET_StopSign) hit |= 2;
-                    }
-                }
-            }
             if (hit) atomicOr(&s_hit[ag], hit);
         }
+        STEP_PHASE(3);
+        // Road boxes of the broadphase cell under each agent's centre, as ONE list of (agent, candidate) items dealt evenly to
+        // all STEP_THREADS threads.  (Rounds 1-4 gave every agent's candidates to the P threads that share the agent: the phase
+        // lasted as long as the fullest cell of the world -- 36 % of a workgroup's time on the bench scene, per-phase clocks of a
+        // -DGD_CLOCKS build -- while most threads had finished.)  The agent threads publish their cell's run of the cell-ordered
+        // candidate arrays and its length, a scan over the agents turns the lengths into offsets, and item t belongs to the
+        // agent whose offset range holds t.  Two items per thread and trip, so that their loads are in flight together.
+        {
+            int cnt = 0, c0 = 0;
+            if (a < A_T && (my_fl & 1) && !(my_fl & 2) && !GD_DIAG_IS(d.step_dbg, 1)) {
+                const float fx = (s_px[a] - gh.ox) * gh.inv_cell, fy = (s_py[a] - gh.oy) * gh.inv_cell;
+                if (gh.nx > 0 && fx >= 0.f && fy >= 0.f && fx < (float)gh.nx && fy < (float)gh.ny) {
+                    const int cell = (int)fy * gh.nx + (int)fx;
+                    c0 = d.cell_off[gh.cell_base + cell];
+                    cnt = d.cell_off[gh.cell_base + cell + 1] - c0;
+                    c0 += gh.item_base;
+                }
+            }
+            // inclusive scan over the lanes of a wave (DPP), the waves of agent threads chained through LDS
+            int incl = cnt;
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+            constexpr int AW = A_T / 64;  // waves of agent threads
+            if (a < A_T && (a & 63) == 63) s_wtot[a >> 6] = incl;
+            if (a == 0) s_nsv[0] = 0;
+            __syncthreads();
+            if (a < A_T) {
+                int base = 0;
+#pragma unroll
+                for (int k = 0; k < AW; k++) base += (k < (a >> 6)) ? s_wtot[k] : 0;
+                s_c0[a] = c0;
+                s_coff[a] = base + incl - cnt;
+            }
+            int total = 0;
+#pragma unroll
+            for (int k = 0; k < AW; k++) total += s_wtot[k];
+            __syncthreads();
+#ifdef GD_CLOCKS
+            if (a == 0) atomicAdd(&g_step_cnt[0], (unsigned long long)total);
+#endif
+            // the exact test of one (agent, box) pair: the box's 14 floats (a gather), the agent's from LDS
+            auto box_test = [&](unsigned int entry) {
+#ifdef GD_CLOCKS
+                atomicAdd(&g_step_cnt[1], 1ull);
+#endif
+                const int g = (int)(entry & 0xffu), rtype = (int)(entry >> 28);
+                const size_t r = (size_t)(bbase + (int)((entry >> 8) & 0xfffffu));
+                const float4 q1 = d.boxes[r * 5 + 1], q2 = d.boxes[r * 5 + 2], q3 = d.boxes[r * 5 + 3], q4 = d.boxes[r * 5 + 4];
+                const float tmp[16] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
+                Obb ro, me;
+                float *of = reinterpret_cast<float *>(&ro), *mf = reinterpret_cast<float *>(&me);
+#pragma unroll
+                for (int k = 0; k < 14; k++) { of[k] = tmp[k]; mf[k] = s_obb[k][g]; }
+                if (obb_collided(me, ro)) atomicOr(&s_hit[g], 1 | ((rtype > ET_None && rtype <= ET_StopSign) ? 2 : 0));
+            };
+            // U items per thread and trip, their candidate records requested together: the records of a world's cells are spread
+            // over ~0.7 MB per world (every box is listed in the ~9 cells it can reach), 0.7 GB per batch, so each trip is a miss
+            // all the way to HBM and the phase is as long as the number of dependent trips (1,280 items per world on the bench
+            // scene: one trip).  A candidate that passes the cull goes on the workgroup's list of (agent, box) pairs -- one in
+            // fifteen does, and which threads hold them is a matter of luck -- and the exact tests are dealt out again from the list.
+            constexpr int U = SVCAP / STEP_THREADS;
+            int trip = 0;
+#pragma clang loop unroll(disable)
+            for (int t0 = 0; t0 < total; t0 += SVCAP, trip ^= 1) {  // (uniform: the barriers inside are reached by every thread)
+                int agu[U];
+                float4 hdr[U];
+                bool on[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int t = t0 + u * STEP_THREADS + a;
+                    on[u] = t < total;
+                    // the LAST agent whose offset is <= t: agents without candidates share the offset of the next agent that has
+                    // some, and "last" picks that one
+                    int lo = 0;
+#pragma unroll
+                    for (int st = A_T / 2; st > 0; st >>= 1)
+                        if (s_coff[lo + st] <= t) lo += st;
+                    agu[u] = lo;
+                    hdr[u] = d.cell_hdr[on[u] ? s_c0[lo] + (t - s_coff[lo]) : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int g = agu[u];
+                    const unsigned int packed = __float_as_uint(hdr[u].w);  // type | local box index << 8 (engine.cpp)
+                    const int rtype = (int)(packed & 0xffu);
+                    const float dx = s_px[g] - hdr[u].x, dy = s_py[g] - hdr[u].y;
+                    const float rr = (s_rad[g] + hdr[u].z) * 1.001f + 0.01f;
+                    if (on[u] && !collision_pair_filtered(s_etype[g], rtype) && !(dx * dx + dy * dy > rr * rr))
+                        s_sv[atomicAdd(&s_nsv[trip], 1)] = (unsigned int)g | (packed >> 8) << 8 | (packed & 0xfu) << 28;  // at most SVCAP items per trip
+                }
+                __syncthreads();
+                const int nsv = s_nsv[trip];
+                if (a == 0) s_nsv[trip ^ 1] = 0;  // (the next trip's counter: nobody touches it before the barrier below)
+                for (int e = a; e < nsv; e += STEP_THREADS) box_test(s_sv[e]);
+                __syncthreads();
+            }
+        }
         __syncthreads();
+        STEP_PHASE(4);
         if (live && active) {
             const int hit = s_hit[a];
             if (hit & 1) collided = 1;
@@ -476,15 +580,23 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         float *ao = d.abs_obs + i * 14;
         ao[0] = b.px; ao[1] = b.py; ao[2] = b.pz;
         ao[3] = rot.w; ao[4] = rot.x; ao[5] = rot.y; ao[6] = rot.z;
-        ao[7] = quat_to_yaw(rot);
+        ao[7] = theta;
         ao[8] = gx; ao[9] = gy;
         ao[10] = length; ao[11] = width; ao[12] = height;
         ao[13] = (float)s_id[a];
     }
 
+#ifdef GD_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STEP_PHASE(5);
     // ---- collectPartnerObsSystem, :188-240: here, or in k_partner_rows on a stream of its own beside the road kernels ----
     if (!d.p.disableClassicalObs && !d.split_partner)
         partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id);
+#ifdef GD_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STEP_PHASE(6);
 }
 
 // The same rows as a kernel of their own: the engine runs it on a second stream while the road kernels (which do not read the
@@ -509,6 +621,17 @@ __global__ __launch_bounds__(STEP_THREADS) void k_partner_rows(DevSim d) {
 }
 
 }  // namespace
+
+#ifdef GD_CLOCKS
+void step_clocks_read(unsigned long long *out) {  // and zero them; out[8..11] = the counters
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_clk), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_clk), z, sizeof(z));
+    (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_step_cnt), 4 * sizeof(unsigned long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_cnt), z, 4 * sizeof(unsigned long long));
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // launchers

@@ -45,12 +45,27 @@ namespace {
 
 constexpr int K = GD_MAP_OBS_K;
 constexpr int LST = (GD_MAX_ROAD_ENTITIES + GD_LIN_BLK - 1) / GD_LIN_BLK + 15;  // blocks of the largest world
-constexpr int CU = 4;  // cull: batches of 64 blocks requested together
-constexpr int PB = 2;  // scan: passes (of 64 roads) requested together
+#ifndef GD_LIN_CU
+#define GD_LIN_CU 4
+#endif
+#ifndef GD_LIN_PB
+#define GD_LIN_PB 2
+#endif
+#ifndef GD_LIN_GH
+#define GD_LIN_GH 2
+#endif
+#ifndef GD_LIN_WPE
+#define GD_LIN_WPE 5
+#endif
+#ifndef GD_LIN_ABL
+#define GD_LIN_ABL 0  // timing-only builds (results wrong): 1 = no cull / scan (the first K roads), 2 = no row arithmetic, 3 = no stores
+#endif
+constexpr int CU = GD_LIN_CU;  // cull: batches of 64 blocks requested together
+constexpr int PB = GD_LIN_PB;  // scan: passes (of 64 roads) requested together
 static_assert(64 % GD_LIN_BLK == 0, "whole blocks per pass");
 
 template <int A_T>
-__global__ __launch_bounds__(256) void k_map_obs_linear(DevSim d) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GD_LIN_WPE))) void k_map_obs_linear(DevSim d) {
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int wg = d.lin_groups[blockIdx.x];
     if (wg < 0) return;  // filler entry (the XCD classes hold different numbers of workgroups)
@@ -101,7 +116,10 @@ __global__ __launch_bounds__(256) void k_map_obs_linear(DevSim d) {
         int count = 0;
         const float dxo = fmaxf(fmaxf(bb.x - ex, ex - bb.z), 0.f), dyo = fmaxf(fmaxf(bb.y - ey, ey - bb.w), 0.f);
         const bool in_reach = R > 0 && !(dxo * dxo + dyo * dyo > reach * reach);  // (NaN poses scan, like the reference's `dist > radius`)
-        if (in_reach) {
+        if (GD_LIN_ABL == 1) {
+            for (int j = lane; j < K; j += 64) sel[j] = (unsigned short)min(j, R - 1);
+            count = min(K, R);
+        } else if (in_reach) {
             // CULL: lane q takes block b0 + q of the world's road blocks (GD_LIN_BLK consecutive roads inside a circle); a block
             // farther from the agent than its circle's radius + the observation radius holds no road in reach.  The surviving
             // blocks are listed in ascending order (one ballot per 64 blocks = 1024 roads).
@@ -167,25 +185,41 @@ __global__ __launch_bounds__(256) void k_map_obs_linear(DevSim d) {
         // ---- the agent's K rows ----
         constexpr int NP = (K + 63) / 64;
         static_assert(K % 4 == 0, "whole 16-byte pieces");
-        float4 q0[NP], q1[NP];
-#pragma unroll
-        for (int pz = 0; pz < NP; pz++) {  // every gather of the agent requested at once
-            const int sl = pz * 64 + lane;
-            const int r = r0 + (sl < count ? (int)sel[sl] : 0);
-            q0[pz] = d.road_rec[(size_t)r * 2];
-            q1[pz] = d.road_rec[(size_t)r * 2 + 1];
-        }
         float *rows_out = d.agent_map + i * (size_t)(K * 9);
         typedef float f4 __attribute__((ext_vector_type(4)));
+        constexpr int GH = GD_LIN_GH < NP ? GD_LIN_GH : NP;  // blocks of 64 rows whose gathers are requested together
 #pragma unroll
-        for (int pz = 0; pz < NP; pz++) {
-            const int sl = pz * 64 + lane;
-            road_row(stage + lane * 9, sl < count, false, ex, ey, iw, -iz, q0[pz], q1[pz]);
-            wave_sync();
-            const int pieces = min(64, K - pz * 64) * 9 / 4;
-            for (int q = lane; q < pieces; q += 64)
-                __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(rows_out + pz * 576 + q * 4));
-            wave_sync();
+        for (int h = 0; h < NP; h += GH) {
+            float4 q0[GH], q1[GH];
+#pragma unroll
+            for (int g = 0; g < GH; g++) {
+                const int sl = (h + g) * 64 + lane;
+                const int r = r0 + (sl < count ? (int)sel[sl] : 0);
+                q0[g] = d.road_rec[(size_t)r * 2];
+                q1[g] = d.road_rec[(size_t)r * 2 + 1];
+            }
+#pragma unroll
+            for (int g = 0; g < GH; g++) {
+                const int pz = h + g;
+                if (pz >= NP) break;
+                const int sl = pz * 64 + lane;
+                if (GD_LIN_ABL == 2) {
+                    float *o = stage + lane * 9;
+                    o[0] = q0[g].x; o[1] = q0[g].y; o[2] = q0[g].z; o[3] = q0[g].w; o[4] = q1[g].x; o[5] = q1[g].y; o[6] = q1[g].z; o[7] = q1[g].w; o[8] = ex;
+                } else {
+                    road_row(stage + lane * 9, sl < count, false, ex, ey, iw, -iz, q0[g], q1[g]);
+                }
+                wave_sync();
+                const int pieces = min(64, K - pz * 64) * 9 / 4;
+                for (int q = lane; q < pieces; q += 64) {
+                    if (GD_LIN_ABL == 3) {
+                        if (stage[q * 4] == 12345.678f) rows_out[0] = 1.f;  // (keeps the row arithmetic alive)
+                        continue;
+                    }
+                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(rows_out + pz * 576 + q * 4));
+                }
+                wave_sync();
+            }
         }
         if (lane == 0)
             d.pose_stamp[i] = make_uint4(__float_as_uint(ex), __float_as_uint(ey), __float_as_uint(p.qw), __float_as_uint(p.qz));

@@ -6,4 +6,4 @@
 cd "$(dirname "$0")/../gpudrive_lab_amd/csrc" || exit 1
 NAME=$1; shift
 mkdir -p ../../build/expt
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" --offload-arch=gfx950 -shared -o ../../build/expt/expt_$NAME.so kernels.hip map_obs.hip map_obs_rank.hip bev_lidar.hip pack_obs.hip episode.hip engine.cpp scene.cpp scene_cache.cpp
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" --offload-arch=gfx950 -shared -o ../../build/expt/expt_$NAME.so $(sed -n 's/^SRCS := //p' Makefile)
