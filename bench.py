@@ -231,10 +231,14 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     roads = int(shape[:, 1].sum())
     batches = action_batches(args.worlds, args.agents, device, seed=1234 + rank)
     all_worlds = np.arange(args.worlds, dtype=np.int32)
-    tracker = None
+    tracker, direct = None, False
     if workload == "rl_loop":
         from gpudrive_lab_amd.episode import EpisodeTracker
         tracker = EpisodeTracker(sim)
+        # set order (and the linear scan): the packed observation is written where the rows are produced, and the raw partner /
+        # road rows -- which nothing in this loop reads -- are not written at all (gd_attach_packed); the reference's row order
+        # keeps the second pass (k_pack_obs)
+        direct = sim.direct_pack(only=True)
 
     gc_ms = [0.0]
     spin_steps = [0]
@@ -303,7 +307,8 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         padded_agent_steps_per_s=world * args.worlds * args.agents * args.steps / elapsed,
         timed_region=dict(graph_steps=graph_steps, plain_steps=plain_steps, episode_resets=args.steps // EPISODE),
         gc_ms_in_timed_stretches=gc_ms[0], spin_up_steps=spin_steps[0],
-        worlds=args.worlds,
+        worlds=args.worlds, packed_observation="written by the step (gd_attach_packed, raw partner / road rows not written)" if direct
+        else ("second pass over the raw tensors (k_pack_obs)" if tracker is not None else None),
     )
     road_kernel = "k_map_obs_linear" if linear else "k_map_obs+k_map_rows"
     names = {0: "k_world_step", 1: road_kernel}
@@ -539,7 +544,7 @@ def main():
                          "(raw = every agent slot's packed observation, compact = controlled agents only), overlapped with the next step")
     ap.add_argument("--gather-steps", type=int, default=30)
     ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop,synthetic_128,waymo_raw,synthetic_set,waymo_set,cfg3_set,"
-                                            "synthetic_linear,waymo_linear,ppo_default",
+                                            "synthetic_linear,waymo_linear,ppo_default,rl_loop_set",
                     help="first = primary; synthetic | waymo | cfg3 | lidar (Waymo tiles + 360-degree LiDAR) | bev | rl_loop | "
                          "waymo_raw (the Waymo tiles with unreduced polylines, the setting of the reference's C++ tests); "
                          "a _128 suffix = 128 agent slots per world (the fork's kMaxAgentCount), a _set suffix = the same scenes "
@@ -659,7 +664,7 @@ def main():
             "allgather": primary.get("allgather"),
             "cpu_baseline": cpu,
             "other_workloads": [
-                {k: r[k] for k in ("workload", "knn_order", "worlds", "agent_steps_per_s", "padded_agent_steps_per_s", "ms_per_step",
+                {k: r[k] for k in ("workload", "knn_order", "worlds", "packed_observation", "agent_steps_per_s", "padded_agent_steps_per_s", "ms_per_step",
                                    "ms_per_step_events", "gc_ms_in_timed_stretches", "spin_up_steps", "overlapped_kernels", "kernels_sum_us", "live_agents_per_rank", "live_agents_with_roads_in_reach", "road_entities_per_rank",
                                    "roofline", "kernels", "other_rooflines")}
                 for r in results[1:]],

@@ -86,7 +86,7 @@ class GdEpisodeBuffers(C.Structure):
 # every symbol include/gpudrive_amd.h declares
 SYMBOLS = [
     "gd_version", "gd_last_error", "gd_default_params", "gd_tensor_shape", "gd_create", "gd_destroy",
-    "gd_step", "gd_reset", "gd_set_maps", "gd_delete_agents", "gd_tensor", "gd_pack_observations",
+    "gd_step", "gd_reset", "gd_set_maps", "gd_delete_agents", "gd_tensor", "gd_pack_observations", "gd_attach_packed",
     "gd_expert_actions", "gd_advance_log_playback", "gd_episode_step", "gd_sync",
     "gd_set_stream", "gd_attach_bev", "gd_stat",
     "gd_kernel_timing_enable", "gd_kernel_timing_read", "gd_debug_get_state", "gd_debug_set_state", "gd_debug_road_path",
@@ -136,6 +136,8 @@ def lib():
     L.gd_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(GdTensorDesc)]
     L.gd_sync.argtypes = [C.c_void_p]
     L.gd_pack_observations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.gd_attach_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    L.gd_attach_packed.restype = C.c_int
     L.gd_episode_step.argtypes = [C.c_void_p, C.POINTER(GdEpisodeConfig), C.POINTER(GdEpisodeBuffers)]
     L.gd_scene_cache_write.argtypes = [C.c_char_p, C.c_float, C.c_char_p]
     L.gd_expert_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -740,6 +740,17 @@ struct gd_sim {
             if (!list.empty()) HIP_CHECK(hipMemcpy(d.lin_groups, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice));
         }
         launch(gd::KERNEL_PADDING, false);
+        // the packed observation's rows of padding agents come from the raw padding rows just written (the live agents' rows are
+        // written by the reset pass that follows every rebuild)
+        if (d.pack) gd::launch_pack_obs(d, stream, d.pack);
+    }
+
+    // the packed observation can be written where the rows are produced when the road kernel of this configuration stores the
+    // rows itself: the linear scan, and set order with its fused write-out
+    bool direct_pack_supported() const {
+        if (params.disableClassicalObs) return false;
+        if (params.roadObservationAlgorithm != GD_ROADS_K_NEAREST) return d.lin_on != 0;
+        return d.knn_order == GD_KNN_SET_ORDER && d.set_fused_rows != 0;
     }
 
     // Uniform grid over the (x, y) of ALL roads of world w: cells of at least 16 m, at most 64 x 64 of them; a road
@@ -1134,11 +1145,48 @@ int gd_tensor(gd_sim *s, int32_t id, gd_tensor_desc *out) {
 int gd_pack_observations(gd_sim *s, float *out, int64_t out_bytes) {
     if (!s || !out) return fail(GD_ERR_INVALID, "gd_pack_observations: null argument");
     const int64_t D = 6 + static_cast<int64_t>(s->A - 1) * 6 + GD_MAP_OBS_K * 13;
-    if (out_bytes < static_cast<int64_t>(s->W) * s->A * D * 4)
-        return fail(GD_ERR_INVALID, "gd_pack_observations: output buffer too small");
+    const int64_t need = static_cast<int64_t>(s->W) * s->A * D * 4;
+    if (out_bytes < need) return fail(GD_ERR_INVALID, "gd_pack_observations: output buffer too small");
     return guarded([&]() {
+        if (s->d.pack) {  // the step already wrote it (gd_attach_packed): nothing to do, or a copy for another buffer
+            if (out != s->d.pack) HIP_CHECK(hipMemcpyAsync(out, s->d.pack, need, hipMemcpyDeviceToDevice, s->stream));
+            return;
+        }
         gd::launch_pack_obs(s->d, s->stream, out);
         HIP_CHECK(hipGetLastError());
+    });
+}
+
+int gd_attach_packed(gd_sim *s, float *out, int64_t out_bytes, int32_t only) {
+    if (!s) return fail(GD_ERR_INVALID, "gd_attach_packed: null sim");
+    const int64_t D = 6 + static_cast<int64_t>(s->A - 1) * 6 + GD_MAP_OBS_K * 13;
+    if (out && out_bytes < static_cast<int64_t>(s->W) * s->A * D * 4)
+        return fail(GD_ERR_INVALID, "gd_attach_packed: output buffer too small");
+    if (out && !s->direct_pack_supported())
+        return fail(GD_ERR_UNSUPPORTED, "gd_attach_packed: this configuration's road kernel does not store the rows itself (reference "
+                                        "row order of the k-NN selection, or GPUDRIVE_SET_FUSED_ROWS=0 / GPUDRIVE_LINEAR_LEGACY=1): use "
+                                        "gd_pack_observations");
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->drop_graph();
+        if (!out) {  // detach: the raw tensors are written again from the next pass on; bring them up to date now
+            s->d.pack = nullptr;
+            s->d.pack_only = 0;
+            HIP_CHECK(hipMemsetAsync(s->d.pose_stamp, 0xff, sizeof(uint4) * static_cast<size_t>(s->W) * s->A, s->stream));
+            s->reset_flagged(false);
+            return;
+        }
+        // everything once from the raw tensors (the padding agents' rows never change between rebuilds); then every pass of the
+        // step kernels writes the live agents' rows in place.  Every pose stamp dies: the next pass writes every live agent's
+        // road columns, whatever was skipped before.
+        s->d.pack = nullptr;
+        s->d.pack_only = 0;
+        HIP_CHECK(hipMemsetAsync(s->d.pose_stamp, 0xff, sizeof(uint4) * static_cast<size_t>(s->W) * s->A, s->stream));
+        s->reset_flagged(false);               // raw tensors up to date (a previous pack_only attachment left them stale)
+        gd::launch_pack_obs(s->d, s->stream, out);
+        HIP_CHECK(hipGetLastError());
+        s->d.pack = out;
+        s->d.pack_only = only ? 1 : 0;
     });
 }
 

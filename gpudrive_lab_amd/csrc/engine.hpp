@@ -127,6 +127,11 @@ struct DevSim {
     // x = 0xffffffff: none (set for every agent whenever worlds are rebuilt -- roads or agent slots may have changed)
     uint4 *pose_stamp;             // [W][A]
     int pose_skip;                 // 0: GPUDRIVE_NO_POSE_SKIP=1 -- every live agent's rows are rewritten on every step
+    // packed observation written where the raw rows are produced (gd_attach_packed): [W][A][6 + (A-1)*6 + K*13], or null.
+    // pack_only: the raw partner and road tensors of live agents are NOT written any more (a learner that only reads the
+    // packed tensor; the padding agents' rows, written when the worlds are built, stay valid)
+    float *pack;
+    int pack_only;
     unsigned long long *stat_skipped;  // [GD_SKIP_SLOTS] agents whose rows were left in place since the counters were last read (gd_stat 30
                                        // sums them): every wave adds to the slot of its own index -- one counter for all of them
                                        // serialises ten thousand atomics at one memory channel (measured: 150 us per launch)

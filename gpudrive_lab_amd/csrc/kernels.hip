@@ -8,6 +8,8 @@
 
 #include "engine.hpp"
 #include "gd_math.hpp"
+#include "map_rows.hpp"
+#include "pack_cols.hpp"
 
 namespace gd {
 
@@ -257,6 +259,56 @@ __device__ __forceinline__ void partner_rows(const DevSim &d, int w, int n, int 
 }
 
 
+// The head of the packed observation (gd_attach_packed; pack_cols.hpp): ego (6) | partners (A - 1) x 6 of every live agent,
+// written where the raw rows are produced.  An agent's head is A rows of 6 floats (row 0 the ego columns, row r the partner in
+// slot r - 1) in one contiguous, 16-byte aligned block: a wave takes an agent at a time, 64 rows per pass -- lane r computes row
+// r exactly as partner_rows does and normalises it, the block is laid out in LDS and leaves as whole 16-byte pieces.
+// `s_self`: the agents' raw self-observation columns 0..6 (speed, length, width, -, goal x, goal y, collided), [A][8].
+template <int A_T>
+__device__ __forceinline__ void packed_head(const DevSim &d, int w, int n, int a, const float *s_px, const float *s_py,
+                                            const float *s_qw, const float *s_qz, const float *s_speed, const float *s_len,
+                                            const float *s_wid, const float *s_self) {
+    constexpr int D = 6 + (A_T - 1) * 6 + K * 13;
+    __shared__ __attribute__((aligned(16))) float s_head[STEP_THREADS / 64][64 * 6];
+    const int wave = a >> 6, lane = a & 63;
+    float *stage = s_head[wave];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int ego = wave; ego < n; ego += STEP_THREADS / 64) {
+        float *out = d.pack + ((size_t)w * A_T + ego) * D;
+#pragma unroll
+        for (int h = 0; h < A_T / 64; h++) {
+            const int r = h * 64 + lane;
+            float *o = stage + lane * 6;
+            if (r == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) o[c] = pack_ego_col(s_self + ego * 8, c);
+            } else {
+                const int k = r - 1;
+                float raw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // zero_nonexist() / zero(): the columns the pack reads are all zero
+                if (k < n - 1) {
+                    const int j = k < ego ? k : k + 1;
+                    const float ew = s_qw[ego], ez = s_qz[ego];
+                    const V2 rel = rotate_yaw(ew, -ez, s_px[j] - s_px[ego], s_py[j] - s_py[ego]);
+                    if (!(rel.x * rel.x + rel.y * rel.y > d.radius_key_max)) {
+                        const float rw = s_qw[j], rz = s_qz[j], iz = -ez;
+                        const float pw = ew * rw - iz * rz, pz = ew * rz + iz * rw;
+                        const float wz = pw * pz;
+                        float heading;
+                        if (wz != 0.f) heading = atan2f(2.0f * wz, 1.0f - 2.0f * (pz * pz));
+                        else heading = quat_to_yaw_row(quat_mul(quat_inv(quat_from_wz(ew, ez)), quat_from_wz(rw, rz)));
+                        raw[0] = s_speed[j]; raw[1] = rel.x; raw[2] = rel.y; raw[3] = heading; raw[4] = s_len[j]; raw[5] = s_wid[j];
+                    }
+                }
+                pack_partner_row(raw, o);
+            }
+            wave_sync();
+            for (int q = lane; q < 64 * 6 / 4; q += 64)
+                __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(out + h * (64 * 6) + q * 4));
+            wave_sync();
+        }
+    }
+}
+
 template <int A_T, bool MOVE>
 __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     const int w = blockIdx.x, a = threadIdx.x;
@@ -272,6 +324,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     __shared__ int s_etype[A_T], s_id[A_T], s_flags[A_T];  // flags: bit0 active, bit1 static
     __shared__ float s_obb[14][A_T];
     __shared__ int s_hit[A_T];  // collision flags found by the threads sharing an agent
+    __shared__ float s_self[A_T * 8];  // the self-observation rows (packed_head reads them)
     constexpr int SVCAP = 6 * STEP_THREADS;  // candidates looked at per trip of the road-box phase (six per thread)
     __shared__ unsigned int s_sv[SVCAP];  // road boxes that passed the cull: agent | local box index << 8 | entity type << 28
     __shared__ int s_nsv[2];
@@ -576,6 +629,10 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         so[4] = g.x; so[5] = g.y;
         so[6] = collided ? 1.f : 0.f;
         so[7] = (float)s_id[a];
+        if (d.pack != nullptr) {
+            float *ss = s_self + a * 8;
+            ss[0] = s_speed[a]; ss[1] = length; ss[2] = width; ss[3] = height; ss[4] = g.x; ss[5] = g.y; ss[6] = collided ? 1.f : 0.f;
+        }
         // ---- collectAbsoluteObservationsSystem, :769-783 ----
         float *ao = d.abs_obs + i * 14;
         ao[0] = b.px; ao[1] = b.py; ao[2] = b.pz;
@@ -591,8 +648,12 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
 #endif
     STEP_PHASE(5);
     // ---- collectPartnerObsSystem, :188-240: here, or in k_partner_rows on a stream of its own beside the road kernels ----
-    if (!d.p.disableClassicalObs && !d.split_partner)
+    if (!d.p.disableClassicalObs && !d.split_partner && !d.pack_only)
         partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id);
+    if (d.pack != nullptr && !d.p.disableClassicalObs) {
+        __syncthreads();  // the agent threads' self columns
+        packed_head<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_self);
+    }
 #ifdef GD_CLOCKS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

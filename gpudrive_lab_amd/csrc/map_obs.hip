@@ -37,6 +37,7 @@
 #include "engine.hpp"
 #include "gd_math.hpp"
 #include "map_rows.hpp"
+#include "pack_cols.hpp"
 
 #ifdef GD_STAMPS
 // diagnostic build only (tools/stamps.sh): per-workgroup cycle counts of the phases of k_map_obs
@@ -961,8 +962,9 @@ __device__ unsigned long long g_set_clk[8];
 #ifndef GD_SET_WPE
 #define GD_SET_WPE 4
 #endif
-template <int A_T, int NW, bool FUSE>
+template <int A_T, int NW, bool FUSE, bool PACK = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_WPE))) void k_map_obs_set(DevSim d) {
+    static_assert(FUSE || !PACK, "the packed rows are written by the fused write-out");
     using S = SetSel<A_T>;
     constexpr int CAP = S::CAP, BMW = S::BMW;
     constexpr int KR_MAX = 5;  // register slots of the K-th-key search: 64 candidates each
@@ -1365,14 +1367,37 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
         float *stage = ckey;
         float *rows_out = d.agent_map + i * (size_t)(K * 9);
         typedef float f4 __attribute__((ext_vector_type(4)));
+        constexpr int PACK_ROAD0 = 6 + (A_T - 1) * 6, PACK_D = PACK_ROAD0 + K * 13;  // the packed row: ego | partners | road points
+        static_assert(S::CAP >= 64 * 13 && PACK_ROAD0 % 4 == 0 && PACK_D % 4 == 0 && ((K % 64) * 13) % 4 == 0, "the packed rows' staging block; whole 16-byte pieces");
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const int sl = p * 64 + lane;
-            road_row(stage + lane * 9, sl < count, knn, ex, ey, iw, -iz, q0[p], q1[p]);
+            const int nrows = min(64, K - p * 64);
+            if (!PACK) {
+                road_row(stage + lane * 9, sl < count, knn, ex, ey, iw, -iz, q0[p], q1[p]);
+                wave_sync();
+                for (int q = lane; q < nrows * 9 / 4; q += 64)
+                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(rows_out + p * 576 + q * 4));
+                wave_sync();
+                continue;
+            }
+            // PACK (gd_attach_packed): the row in registers, stored raw unless pack_only, then in the packed observation's 13
+            // normalised columns (pack_cols.hpp)
+            float raw[9];
+            road_row(raw, sl < count, knn, ex, ey, iw, -iz, q0[p], q1[p]);
+            if (!d.pack_only) {
+#pragma unroll
+                for (int c = 0; c < 9; c++) stage[lane * 9 + c] = raw[c];
+                wave_sync();
+                for (int q = lane; q < nrows * 9 / 4; q += 64)
+                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(rows_out + p * 576 + q * 4));
+                wave_sync();
+            }
+            pack_road_row(raw, stage + lane * 13);
             wave_sync();
-            const int pieces = min(64, K - p * 64) * 9 / 4;
-            for (int q = lane; q < pieces; q += 64)
-                __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(rows_out + p * 576 + q * 4));
+            float *pout = d.pack + i * (size_t)PACK_D + PACK_ROAD0 + p * (64 * 13);
+            for (int q = lane; q < nrows * 13 / 4; q += 64)
+                __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(pout + q * 4));
             wave_sync();
         }
     }
@@ -1403,6 +1428,11 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         if (d.set_group_count == 0) return;
         const dim3 grid(d.set_group_count);
         if (d.set_fused_rows) {
+            if (d.pack != nullptr) {
+                if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4, true, true>), grid, dim3(256), 0, st, d);
+                else hipLaunchKernelGGL((k_map_obs_set<128, 4, true, true>), grid, dim3(256), 0, st, d);
+                return;
+            }
             if (d.A == 64) hipLaunchKernelGGL((k_map_obs_set<64, 4, true>), grid, dim3(256), 0, st, d);
             else hipLaunchKernelGGL((k_map_obs_set<128, 4, true>), grid, dim3(256), 0, st, d);
             return;

@@ -28,8 +28,8 @@
 //   * workgroups are dealt to the XCDs by world (engine.cpp lin_groups: workgroup b runs on XCD b % 8, and the list puts
 //     every workgroup of a world at the same b % 8), so that a world's road arrays are fetched into one L2, not eight.
 //
-// With pack != nullptr the wave also (or only: DevSim::pack_only) writes the agent's 200 x 13 normalised road columns of the
-// packed observation (pack_obs.hip), so that a learner that reads packed_observations() does not pay a second pass.
+// With DevSim::pack set (gd_attach_packed) the wave also -- or only: pack_only -- writes the agent's 200 x 13 normalised road
+// columns of the packed observation (pack_cols.hpp), so that a learner that reads packed_observations() pays no second pass.
 //
 // Algorithmic bytes per agent: 8 B per road scanned until K are found + 16 B of pose + 7,200 B of rows (SURVEY.md 8d's
 // contract counts 36 B for every road of the world once per world instead).  Bound: HBM writes.
@@ -38,6 +38,7 @@
 #include "engine.hpp"
 #include "gd_math.hpp"
 #include "map_rows.hpp"
+#include "pack_cols.hpp"
 
 namespace gd {
 
@@ -64,7 +65,7 @@ constexpr int CU = GD_LIN_CU;  // cull: batches of 64 blocks requested together
 constexpr int PB = GD_LIN_PB;  // scan: passes (of 64 roads) requested together
 static_assert(64 % GD_LIN_BLK == 0, "whole blocks per pass");
 
-template <int A_T>
+template <int A_T, bool PACK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GD_LIN_WPE))) void k_map_obs_linear(DevSim d) {
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
     const int wg = d.lin_groups[blockIdx.x];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GD_LIN_WPE)
 
     __shared__ unsigned short s_sel[4][K + 56];                          // the selected road indices of the wave's agent, index order
     __shared__ unsigned short s_lst[4][LST];                             // the blocks of the world's roads that may hold a road in reach
-    __shared__ __attribute__((aligned(16))) float s_stage[4][64 * 9];    // 64 rows on their way out
+    __shared__ __attribute__((aligned(16))) float s_stage[4][64 * 13];   // 64 rows on their way out (9 raw or 13 packed columns)
     unsigned short *sel = s_sel[wave];
     unsigned short *lst = s_lst[wave];
     const int NB = (R + GD_LIN_BLK - 1) / GD_LIN_BLK;
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GD_LIN_WPE)
         wave_sync();
         // ---- the agent's K rows ----
         constexpr int NP = (K + 63) / 64;
-        static_assert(K % 4 == 0, "whole 16-byte pieces");
+        constexpr int PACK_ROAD0 = 6 + (A_T - 1) * 6, PACK_D = PACK_ROAD0 + K * 13;  // the packed row: ego | partners | road points
+        static_assert(K % 4 == 0 && PACK_ROAD0 % 4 == 0 && PACK_D % 4 == 0 && (64 * 13) % 4 == 0 && ((K % 64) * 13) % 4 == 0, "whole 16-byte pieces");
         float *rows_out = d.agent_map + i * (size_t)(K * 9);
         typedef float f4 __attribute__((ext_vector_type(4)));
         constexpr int GH = GD_LIN_GH < NP ? GD_LIN_GH : NP;  // blocks of 64 rows whose gathers are requested together
@@ -203,22 +205,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GD_LIN_WPE)
                 const int pz = h + g;
                 if (pz >= NP) break;
                 const int sl = pz * 64 + lane;
+                float raw[9];
                 if (GD_LIN_ABL == 2) {
-                    float *o = stage + lane * 9;
-                    o[0] = q0[g].x; o[1] = q0[g].y; o[2] = q0[g].z; o[3] = q0[g].w; o[4] = q1[g].x; o[5] = q1[g].y; o[6] = q1[g].z; o[7] = q1[g].w; o[8] = ex;
+                    raw[0] = q0[g].x; raw[1] = q0[g].y; raw[2] = q0[g].z; raw[3] = q0[g].w; raw[4] = q1[g].x; raw[5] = q1[g].y; raw[6] = q1[g].z; raw[7] = q1[g].w; raw[8] = ex;
                 } else {
-                    road_row(stage + lane * 9, sl < count, false, ex, ey, iw, -iz, q0[g], q1[g]);
+                    road_row(raw, sl < count, false, ex, ey, iw, -iz, q0[g], q1[g]);
                 }
-                wave_sync();
-                const int pieces = min(64, K - pz * 64) * 9 / 4;
-                for (int q = lane; q < pieces; q += 64) {
-                    if (GD_LIN_ABL == 3) {
-                        if (stage[q * 4] == 12345.678f) rows_out[0] = 1.f;  // (keeps the row arithmetic alive)
-                        continue;
+                const int nrows = min(64, K - pz * 64);
+                if (!PACK || !d.pack_only) {
+#pragma unroll
+                    for (int c = 0; c < 9; c++) stage[lane * 9 + c] = raw[c];
+                    wave_sync();
+                    for (int q = lane; q < nrows * 9 / 4; q += 64) {
+                        if (GD_LIN_ABL == 3) {
+                            if (stage[q * 4] == 12345.678f) rows_out[0] = 1.f;  // (keeps the row arithmetic alive)
+                            continue;
+                        }
+                        __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(rows_out + pz * 576 + q * 4));
                     }
-                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(rows_out + pz * 576 + q * 4));
+                    wave_sync();
                 }
-                wave_sync();
+                if (PACK) {  // (gd_attach_packed) the same rows in the packed observation's 13 normalised columns (pack_cols.hpp)
+                    pack_road_row(raw, stage + lane * 13);
+                    wave_sync();
+                    float *pout = d.pack + i * (size_t)PACK_D + PACK_ROAD0 + pz * (64 * 13);
+                    for (int q = lane; q < nrows * 13 / 4; q += 64)
+                        __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(pout + q * 4));
+                    wave_sync();
+                }
             }
         }
         if (lane == 0)
@@ -232,8 +246,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GD_LIN_WPE)
 void launch_map_obs_linear(const DevSim &d, hipStream_t st) {
     if (d.lin_group_count == 0) return;
     const dim3 grid(d.lin_group_count);
-    if (d.A == 64) hipLaunchKernelGGL((k_map_obs_linear<64>), grid, dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((k_map_obs_linear<128>), grid, dim3(256), 0, st, d);
+    if (d.pack != nullptr) {
+        if (d.A == 64) hipLaunchKernelGGL((k_map_obs_linear<64, true>), grid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((k_map_obs_linear<128, true>), grid, dim3(256), 0, st, d);
+        return;
+    }
+    if (d.A == 64) hipLaunchKernelGGL((k_map_obs_linear<64, false>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((k_map_obs_linear<128, false>), grid, dim3(256), 0, st, d);
 }
 
 }  // namespace gd

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "engine.hpp"
+#include "pack_cols.hpp"
 
 namespace gd {
 
@@ -17,48 +18,20 @@ namespace {
 #define GD_PACK_PARTS 64  // workgroups per world of k_pack_obs: one agent slot each (4 or 16 per world measured the same within noise)
 #endif
 constexpr int K = GD_MAP_OBS_K;
-constexpr float kAgentScale = GD_VEHICLE_SCALE;  // madrona_gpudrive.vehicleScale
-constexpr float kTwoPi = 6.283185307179586f;     // constants.MAX_ORIENTATION_RAD = 2 * np.pi
-
-__device__ __forceinline__ float norm_min_max(float x, float lo, float hi) {  // gpudrive/utils/geometry.py:15-26
-    return 2.f * ((x - lo) / (hi - lo)) - 1.f;
-}
-
 // Per agent: the source rows (63 x 9 partner floats, 200 x 9 road floats: 9.5 KB) are staged in LDS with
 // coalesced loads (16-byte loads for the road rows), then one thread per FOUR consecutive output floats
 // (rows are 2984 floats, so float4 groups never straddle a row) computes from LDS and issues one 16-byte
 // store: both directions of the 1.4 GB this pass moves per step at 1024 x 64 are fully coalesced.  Every
-// output element costs ONE true division: numerator and divisor are selected per column first.
+// output element costs ONE true division: numerator and divisor are selected per column first (pack_cols.hpp).
 template <int A_T>
 __device__ __forceinline__ float pack_element(const float *self, const float *partner, const float *road, int j) {
-    if (j < 6) {  // ego, env_torch.py:756-800
-        switch (j) {
-            case 0: return self[0] / 100.f;
-            case 1: return (self[1] * kAgentScale) / 30.f;
-            case 2: return (self[2] * kAgentScale) / 15.f;
-            case 3: return norm_min_max(self[4], -1000.f, 1000.f);
-            case 4: return norm_min_max(self[5], -1000.f, 1000.f);
-            default: return self[6];
-        }
-    }
-    if (j < 6 + (A_T - 1) * 6) {  // partners, env_torch.py:828-858
+    if (j < 6) return pack_ego_col(self, j);
+    if (j < 6 + (A_T - 1) * 6) {
         const int p = j - 6, k = p / 6, c = p - k * 6;
-        const float x = partner[k * 9 + c];
-        const bool nm = c == 1 || c == 2;
-        const float num = nm ? x - (-1000.f) : (c >= 4 ? x * kAgentScale : x);
-        const float den = c == 0 ? 100.f : (nm ? 1000.f - (-1000.f) : (c == 3 ? kTwoPi : (c == 4 ? 30.f : 15.f)));
-        const float q = num / den;
-        return nm ? 2.f * q - 1.f : q;
+        return pack_partner_col(partner[k * 9 + c], c);
     }
-    // road points, env_torch.py:860-896 (one-hot over 7 road point types)
     const int p = j - 6 - (A_T - 1) * 6, k = p / 13, c = p - k * 13;
-    const float x = road[k * 9 + (c < 6 ? c : 6)];
-    if (c >= 6) return (int)(long long)x == c - 6 ? 1.f : 0.f;
-    const bool nm = c < 2;
-    const float num = nm ? x - (-1000.f) : x;
-    const float den = nm ? 1000.f - (-1000.f) : (c < 5 ? 100.f : kTwoPi);
-    const float q = num / den;
-    return nm ? 2.f * q - 1.f : q;
+    return pack_road_col(road[k * 9 + (c < 6 ? c : 6)], c);
 }
 
 template <int A_T>

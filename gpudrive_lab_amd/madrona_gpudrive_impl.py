@@ -14,7 +14,8 @@ Build-specific options that the reference's constructor does not have can also b
 environment, so that an unchanged `gpudrive.env.base_env` (which passes none of them,
 gpudrive/env/base_env.py:176-190) reaches them: GPUDRIVE_MAX_AGENTS (64 | 128), GPUDRIVE_KNN_ORDER
 (0 reference heap order | 1 set order), GPUDRIVE_LIDAR_HALF_ANGLE (radians; unset = the reference's
-pi/3), GPUDRIVE_SYNC_STEP (1 = blocking).  The BEV tensor needs no option: it is created on the first
+pi/3), GPUDRIVE_SYNC_STEP (1 = blocking), GPUDRIVE_DIRECT_PACK (1 | 2: the packed observation written by the step itself,
+`SimManager.direct_pack`).  The BEV tensor needs no option: it is created on the first
 `bev_observation_tensor()` call.
 """
 import ctypes as C
@@ -238,6 +239,10 @@ class SimManager:
             _capi.check(self._L.gd_create(C.byref(cfg), C.byref(cparams), arr, C.byref(h)), "gd_create")
             self._stream = cfg.stream  # the stream the engine launches on until _bind_stream() sees another one
         self._h = h
+        self._direct = None
+        dp = os.environ.get("GPUDRIVE_DIRECT_PACK", "0")
+        if dp not in ("", "0"):
+            self.direct_pack(only=dp == "2")
         if self._sync:
             self.sync()
 
@@ -322,6 +327,36 @@ class SimManager:
         self._bind_stream()
         _capi.check(self._L.gd_pack_observations(self._h, out.data_ptr(), out.numel() * 4), "gd_pack_observations")
         return out
+
+    def direct_pack(self, only=True, out=None):
+        """Extension: from now on the step itself writes the packed observation (ego + partner columns by the state kernel,
+        the 200 x 13 road columns by the road kernel) instead of `packed_observations()` making a second pass over the raw
+        tensors; `packed_observations()` then just returns that tensor.  `only=True`: the raw partner / road rows of live
+        agents are no longer written (a learner that reads nothing else).  Returns False -- and changes nothing -- when this
+        configuration's road kernel does not store the rows itself (k-NN selection in the reference's row order): the
+        second-pass `packed_observations()` keeps working there.  GPUDRIVE_DIRECT_PACK=1 (raw rows kept) / 2 (only) at
+        construction does the same for an unchanged caller."""
+        import torch
+        D = 6 + (self._A - 1) * 6 + kMaxAgentMapObservationsCount * 13
+        if out is None:
+            out = getattr(self, "_packed", None)
+            if out is None:
+                out = torch.empty((self._W, self._A, D), dtype=torch.float32, device=self._device)
+        assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == self._W * self._A * D
+        self._bind_stream()
+        rc = self._L.gd_attach_packed(self._h, out.data_ptr(), out.numel() * 4, 1 if only else 0)
+        if rc == _capi.GD_ERR_UNSUPPORTED:
+            return False
+        _capi.check(rc, "gd_attach_packed")
+        self._packed = self._direct = out
+        return True
+
+    def direct_pack_off(self):
+        """Back to the raw tensors + the second-pass `packed_observations()`."""
+        if getattr(self, "_direct", None) is not None:
+            self._bind_stream()
+            _capi.check(self._L.gd_attach_packed(self._h, None, 0, 0), "gd_attach_packed")
+            self._direct = None
 
     def expert_actions(self):
         """Extension: what `GPUDriveTorchEnv.get_expert_actions()` returns (reference

@@ -155,6 +155,16 @@ int gd_tensor(gd_sim *sim, int32_t id, gd_tensor_desc *out);
  * out[W][A][6 + (A-1)*6 + 200*13] f32 = ego | partners | road points (type one-hot over 7).
  * `out` is a device pointer of at least out_bytes bytes. */
 int gd_pack_observations(gd_sim *sim, float *out, int64_t out_bytes);
+/* The same tensor written WHERE THE ROWS ARE PRODUCED instead of by a second pass over the exported tensors: from this call on
+ * every step / reset pass writes the live agents' packed rows straight into `out` (k_world_step: ego + partner columns; the
+ * road kernel: the 200 x 13 road columns), bit-identical to gd_pack_observations on the same state; `out` must stay valid
+ * until it is detached (out = NULL) or the simulator is destroyed.  only != 0: the raw partner_observations and
+ * agent_roadmap rows of live agents are no longer written (for a learner that reads nothing but the packed tensor --
+ * gpudrive/env/env_torch.py:756-896 is the only consumer of those rows in the reference's PPO loop); only = 0 keeps them.
+ * GD_ERR_UNSUPPORTED when this configuration's road kernel does not store the rows itself (the k-NN selection in the
+ * reference's row order): keep calling gd_pack_observations there.  With a buffer attached gd_pack_observations is a no-op
+ * for that buffer and a device copy for any other. */
+int gd_attach_packed(gd_sim *sim, float *out, int64_t out_bytes, int32_t only);
 /* Expert-action export: GPUDriveTorchEnv.get_expert_actions()
  * (gpudrive/env/env_torch.py:1445-1509 over gpudrive/datatypes/trajectory.py:24-41) in one pass over the
  * expert trajectory rows.  Device pointers, any of them may be NULL:

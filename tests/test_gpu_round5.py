@@ -173,3 +173,74 @@ def test_pose_stamps_die_with_the_world(oracle_mod, tmp_path):
     P.lockstep(gpu, orc, 60, 0, seed=5)   # through the episode's end: finished agents are parked at the padding position
     torch.cuda.synchronize()
     gpu.close()
+
+
+DIRECT_PACK = [
+    ("set_order_64", [TEST_JSON, SCENE_407, SCENE_4], 64, 1, dict(WAYMO_LINEAR, roadObservationAlgorithm=0)),
+    ("set_order_128", [SCENE_4, SCENE_407], 128, 1, dict(WAYMO_LINEAR, roadObservationAlgorithm=0, collisionBehaviour=0)),
+    ("linear_ppo_default", [TEST_JSON, SCENE_407, SCENE_4], 128, 0, PPO_DEFAULT),
+    ("linear_64_set_order_flag", [SCENE_407, SCENE_4], 64, 1, WAYMO_LINEAR),
+]
+
+
+@pytest.mark.parametrize("name,scenes,slots,knn_order,kw", DIRECT_PACK, ids=[c[0] for c in DIRECT_PACK])
+def test_packed_observation_written_by_the_step_equals_the_second_pass(name, scenes, slots, knn_order, kw):
+    """gd_attach_packed: the packed observation written where the rows are produced (k_world_step: ego + partner columns;
+    the road kernel: 200 x 13 road columns) must be bit-identical to k_pack_obs's second pass over the raw tensors -- which
+    tests/golden/obs_pack_golden.npz pins to the reference's own gpudrive/datatypes code -- on three simulators fed the
+    same actions: raw tensors + second pass, direct with the raw rows kept, direct ONLY.  Through steps, a partial reset, a
+    set_maps and a deleteAgents; padding agents' rows included."""
+    ref = P.make_gpu_sim(scenes, max_agents=slots, knn_order=knn_order, **kw)
+    both = P.make_gpu_sim(scenes, max_agents=slots, knn_order=knn_order, **kw)
+    only = P.make_gpu_sim(scenes, max_agents=slots, knn_order=knn_order, **kw)
+    assert both.direct_pack(only=False) and only.direct_pack(only=True)
+    sims = [ref, both, only]
+    W = len(scenes)
+    rng = np.random.default_rng(3)
+
+    def check(tag):
+        want = _bits(ref.packed_observations())
+        for s, nm in ((both, "raw rows kept"), (only, "packed only")):
+            got = _bits(s.packed_observations())
+            assert got.shape == want.shape
+            if not np.array_equal(got, want):
+                bad = np.argwhere(got != want)
+                raise AssertionError("%s (%s): %d packed elements differ, first at %s" % (tag, nm, len(bad), bad[0]))
+        for t in ("partner_observations_tensor", "agent_roadmap_tensor", "self_observation_tensor"):
+            assert np.array_equal(_bits(getattr(both, t)()), _bits(getattr(ref, t)())), "%s: %s differs with the raw rows kept" % (tag, t)
+
+    check("t = 0")
+    for step in range(24):
+        act = P.random_actions(rng, W, slots, 0)
+        for s in sims:
+            RC.write_actions(s, act)
+            s.step()
+        if step == 7:
+            for s in sims:
+                s.reset([W - 1])
+        if step == 12:
+            new = scenes[1:] + scenes[:1]
+            for s in sims:
+                s.set_maps(new)
+        if step == 17:
+            ids = RC.as_np(ref.absolute_self_observation_tensor())[0, :2, 13].astype(int).tolist()
+            for s in sims:
+                s.deleteAgents({0: ids})
+        check("step %d" % (step + 1))
+    # switching it off again: the raw rows are brought up to date at once
+    only.direct_pack_off()
+    for t in ("partner_observations_tensor", "agent_roadmap_tensor"):
+        assert np.array_equal(_bits(getattr(only, t)()), _bits(getattr(ref, t)())), t
+    for s in sims:
+        s.close()
+
+
+def test_direct_pack_is_refused_where_the_road_kernel_does_not_store_the_rows():
+    """Reference row order of the k-NN selection: gd_attach_packed answers GD_ERR_UNSUPPORTED, nothing changes, and the
+    second-pass packed_observations() keeps working."""
+    kw = dict(WAYMO_LINEAR, roadObservationAlgorithm=0)
+    gpu = P.make_gpu_sim([SCENE_407], max_agents=64, knn_order=0, **kw)
+    before = _bits(gpu.packed_observations()).copy()
+    assert gpu.direct_pack(only=True) is False
+    assert np.array_equal(_bits(gpu.packed_observations()), before)
+    gpu.close()
