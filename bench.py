@@ -383,10 +383,13 @@ def _bench_workload(name, args, rank, local_rank, world, device):
                            algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt[road_kernel]["avg_us"],
                            design_min_bytes_per_launch=design_min,
                            survey_bytes_per_launch=survey_bytes, reference_bytes_per_launch=reference_bytes,
+                           frac_of_reference_bytes=(reference_bytes / avg_s / 1e9 / HBM_PEAK_GBS) if avg_s > 0 else 0.0,
                            roads_visited_until_k=scanned, agents_skipped_per_launch=skipped_per_launch,
                            skip_note="an agent whose pose bits equal the ones its rows were last written for is not rewritten (parked / "
-                                     "finished agents); its 7216 B are NOT in algorithmic_bytes_per_launch; reference_bytes_per_launch "
-                                     "counts every live agent",
+                                     "finished agents); its 7216 B are NOT in algorithmic_bytes_per_launch, which `achieved` and `frac` "
+                                     "price (bytes the kernel moved); reference_bytes_per_launch counts every live agent like the "
+                                     "reference's loop does, and frac_of_reference_bytes = that / time / peak can exceed what any "
+                                     "memory system delivers -- it is the speed-up over rewriting everything, not a bandwidth",
                            denominators="algorithmic_bytes_per_launch = SURVEY 8d's contract (36 R_w + 7216 N_w per world-step); "
                                         "design_min_bytes_per_launch = this layout's own floor (8 R_w scanned once per world + 32 B x "
                                         "min(R_w, K) gathered records + 7216 N_w written): traffic >= the second, not necessarily the first")

@@ -512,8 +512,17 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     const size_t e = wa * K + qf;  // a multiple of four: both loads are aligned
     const uint2 idx4 = *reinterpret_cast<const uint2 *>(d.sel_idx + e);
     const unsigned int slot4 = *reinterpret_cast<const unsigned int *>(d.sel_slot + e);
-    const bool on = act && a0 + al < agents && cnt >= 0;  // rows of padding agents are written at reset (k_init_padding_rows)
-    if (act && qf == 0) s_on[al] = on ? 1 : 0;
+    // rows already written for exactly this pose (engine.hpp pose_stamp: it dies with the world's roads) are left in place: an
+    // agent that did not move -- a parked car, a finished agent at the padding position -- selects the same roads and sees them
+    // in the same place
+    const uint4 st = d.pose_stamp[wa];
+    const bool same = d.pose_skip != 0 && st.x != 0xffffffffu && st.x == __float_as_uint(pose.x) && st.y == __float_as_uint(pose.y) &&
+                      st.z == __float_as_uint(pose.z) && st.w == __float_as_uint(pose.w);
+    const bool on = act && a0 + al < agents && cnt >= 0 && !same;  // rows of padding agents are written at reset (k_init_padding_rows)
+    if (act && qf == 0) {
+        s_on[al] = on ? 1 : 0;
+        if (a0 + al < agents && cnt >= 0 && same) atomicAdd(d.stat_skipped + (blockIdx.x & (GD_SKIP_SLOTS - 1)), 1ull);
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int q = qf + u;
@@ -547,6 +556,7 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
         if (s_on[q / PPA] != 0)
             __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + (size_t)q * 4));
     }
+    if (on && qf == 0) d.pose_stamp[wa] = make_uint4(__float_as_uint(pose.x), __float_as_uint(pose.y), __float_as_uint(pose.z), __float_as_uint(pose.w));
 }
 
 // Selection hand-over from a workgroup that holds agents a0 .. a0+na-1 of world w as columns: idx_of(col, s) is the road
@@ -1001,12 +1011,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
     // four waves per SIMD nothing else covers them: what an agent needs is requested while the one before it is still
     // being worked on (pose and last step's bound at the top of the previous agent, the runs before its K-th-key search),
     // and the pieces of a run are requested GD_SET_PB at a time, the next batch before the current one is keyed.
-    struct AgentIn { float ex, ey, qw, qz; float4 pv; };
+    struct AgentIn { float ex, ey, qw, qz; float4 pv; uint4 st; };
     struct Plan { float bound, floor_key; int nrows, run_lo, run_hi; };
     const bool use_grid = knn && R > 0;
     auto load_agent = [&](int a) -> AgentIn {
         const size_t i = (size_t)w * A_T + a;
-        return AgentIn{d.px[i], d.py[i], d.qw[i], d.qz[i], d.knn_prev[i]};
+        return AgentIn{d.px[i], d.py[i], d.qw[i], d.qz[i], d.knn_prev[i], d.pose_stamp[i]};
     };
     // candidates: within the radius AND within what the previous selection allows (the K-th distance is 1-Lipschitz in the
     // agent's position: it also cannot fall below sqrt(T) - |movement|, which gives the search for the new T a narrow
@@ -1045,7 +1055,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
         pl.run_hi = coff[row * g.nx + cx1 + 1];
         return pl;
     };
-    AgentIn nx{0.f, 0.f, 1.f, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    AgentIn nx{0.f, 0.f, 1.f, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), make_uint4(0u, 0u, 0u, 0u)};
+    int skipped = 0;
     Plan npl{kmax, 0.f, 0, 0, 0};
     if (a_first + wave < a_end) {
         nx = load_agent(a_first + wave);
@@ -1059,6 +1070,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
         if (more) nx = load_agent(a + NW);
         const float ex = cur_in.ex, ey = cur_in.ey;
         const float iw = cur_in.qw, iz = -cur_in.qz;  // the INVERSE rotation
+        if (FUSE) {
+            // rows already written for exactly this pose (engine.hpp pose_stamp: it dies with the world's roads) are left in
+            // place: the agent did not move, so it selects the same roads and sees them in the same place (its bound,
+            // knn_prev, stays what it is).  Without the fused write-out k_map_rows decides the same from the header.
+            const uint4 st = cur_in.st;
+            if (d.pose_skip != 0 && st.x != 0xffffffffu && st.x == __float_as_uint(ex) && st.y == __float_as_uint(ey) &&
+                st.z == __float_as_uint(cur_in.qw) && st.w == __float_as_uint(cur_in.qz)) {
+                skipped++;
+                if (more && use_grid) npl = plan(nx);
+                continue;
+            }
+        }
         unsigned short *out = FUSE ? s_sel[wave] : d.sel_idx + i * K;  // the selected road indices, in the mode's order
         int count = 0;
         float kth = __builtin_inff();
@@ -1400,7 +1423,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
                 __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(stage + q * 4), reinterpret_cast<f4 *>(pout + q * 4));
             wave_sync();
         }
+        if (lane == 0)
+            d.pose_stamp[i] = make_uint4(__float_as_uint(ex), __float_as_uint(ey), __float_as_uint(cur_in.qw), __float_as_uint(cur_in.qz));
     }
+    if (FUSE && lane == 0 && skipped) atomicAdd(d.stat_skipped + ((blockIdx.x * NW + wave) & (GD_SKIP_SLOTS - 1)), (unsigned long long)skipped);
 #ifdef GD_CLOCKS
     if (lane == 0)
         for (int k = 0; k < 8; k++) atomicAdd(&g_set_clk[k], (unsigned long long)clk_sum[k]);

@@ -244,3 +244,49 @@ def test_direct_pack_is_refused_where_the_road_kernel_does_not_store_the_rows():
     assert gpu.direct_pack(only=True) is False
     assert np.array_equal(_bits(gpu.packed_observations()), before)
     gpu.close()
+
+
+@pytest.mark.parametrize("mode", ["reference_order_rank_path", "reference_order_history_replay", "set_order_fused", "set_order_row_kernel"])
+def test_rows_left_in_place_are_the_rows_a_rewrite_would_produce(monkeypatch, mode):
+    """Pose stamps in the k-NN modes (k_map_rows for the reference's row order and the unfused set-order write-out, the fused
+    set-order kernel): two simulators on Waymo scenes under the default init rules (parked cars stay Static, finished agents
+    are parked at the padding position), one with GPUDRIVE_NO_POSE_SKIP=1, same actions, free running through a partial
+    reset and a teleport of a few agents: bit-identical road rows at every step, and rows must actually have been skipped."""
+    kw = dict(PPO_DEFAULT, roadObservationAlgorithm=0, collisionBehaviour=0)
+    knn_order = 1 if mode.startswith("set") else 0
+    if mode == "reference_order_rank_path":
+        monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")
+    if mode == "reference_order_history_replay":
+        monkeypatch.setenv("GPUDRIVE_NO_RANK_REPLAY", "1")
+    if mode == "set_order_row_kernel":
+        monkeypatch.setenv("GPUDRIVE_SET_FUSED_ROWS", "0")
+    scenes = [TEST_JSON, SCENE_407, SCENE_4, SCENE_407]
+    skip = P.make_gpu_sim(scenes, max_agents=128, knn_order=knn_order, **kw)
+    monkeypatch.setenv("GPUDRIVE_NO_POSE_SKIP", "1")
+    plain = P.make_gpu_sim(scenes, max_agents=128, knn_order=knn_order, **kw)
+    monkeypatch.delenv("GPUDRIVE_NO_POSE_SKIP")
+    rng = np.random.default_rng(6)
+    skip.stat(30)
+    assert np.array_equal(_bits(skip.agent_roadmap_tensor()), _bits(plain.agent_roadmap_tensor()))
+    for step in range(45):
+        act = P.random_actions(rng, len(scenes), 128, 0)
+        for s in (skip, plain):
+            RC.write_actions(s, act)
+            s.step()
+        if step == 15:
+            for s in (skip, plain):
+                s.reset([0, 3])
+        if step == 25:
+            st = skip.debug_get_state()
+            st[:, 1:4, 0] -= 25.0
+            st[:, 1:4, 3], st[:, 1:4, 6] = np.cos(-0.7), np.sin(-0.7)
+            for s in (skip, plain):
+                s.debug_set_state(st)
+                s.reset([])
+        a, b = _bits(skip.agent_roadmap_tensor()), _bits(plain.agent_roadmap_tensor())
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            raise AssertionError("step %d: %d elements differ, first at %s" % (step + 1, len(bad), bad[0]))
+    assert skip.stat(30) > 0 and plain.stat(30) == 0
+    skip.close()
+    plain.close()
