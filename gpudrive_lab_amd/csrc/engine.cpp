@@ -112,7 +112,7 @@ struct gd_sim {
     std::vector<std::vector<int32_t>> w_rcell_off;
     std::vector<std::vector<uint16_t>> w_rcell_items;
     size_t rcell_cap = 0, ritem_cap = 0;
-    void *d_rcell_off = nullptr, *d_rcell_items = nullptr, *d_rcell_xy = nullptr;
+    void *d_rcell_off = nullptr, *d_rcell_items = nullptr, *d_rcell_xy = nullptr, *d_rcell_pos = nullptr;
     size_t cell_cap = 0, item_cap = 0;
     void *d_cell_off = nullptr, *d_cell_items = nullptr, *d_cell_hdr = nullptr;
     size_t road_cap = 0, box_cap = 0, blk_cap = 0;
@@ -208,6 +208,7 @@ struct gd_sim {
         if (d_rcell_off) (void)hipFree(d_rcell_off);
         if (d_rcell_items) (void)hipFree(d_rcell_items);
         if (d_rcell_xy) (void)hipFree(d_rcell_xy);
+        if (d_rcell_pos) (void)hipFree(d_rcell_pos);
         for (int i = 0; i < kRing; i++) {
             if (h_flags[i]) (void)hipHostFree(h_flags[i]);
             if (flag_ev[i]) (void)hipEventDestroy(flag_ev[i]);
@@ -805,13 +806,16 @@ struct gd_sim {
         if (nitem + 64 > ritem_cap) {
             if (d_rcell_items) (void)hipFree(d_rcell_items);
             if (d_rcell_xy) (void)hipFree(d_rcell_xy);
+            if (d_rcell_pos) (void)hipFree(d_rcell_pos);
             ritem_cap = nitem + nitem / 8 + 128;
             HIP_CHECK(hipMalloc(&d_rcell_items, ritem_cap * sizeof(uint16_t)));
             HIP_CHECK(hipMalloc(&d_rcell_xy, ritem_cap * sizeof(float) * 2));
+            HIP_CHECK(hipMalloc(&d_rcell_pos, ritem_cap * sizeof(uint16_t)));
         }
         std::vector<int32_t> co(ncell);
         std::vector<uint16_t> ci(nitem);
         std::vector<float> cxy(nitem * 2);
+        std::vector<uint16_t> cpos(nitem);  // (a world's items are its roads, one each: item_base is also its first road)
         for (int w = 0; w < W; w++) {
             std::copy(w_rcell_off[w].begin(), w_rcell_off[w].end(), co.begin() + w_rgrid[w].cell_base);
             std::copy(w_rcell_items[w].begin(), w_rcell_items[w].end(), ci.begin() + w_rgrid[w].item_base);
@@ -819,12 +823,15 @@ struct gd_sim {
                 const size_t r = w_rcell_items[w][k], o = (static_cast<size_t>(w_rgrid[w].item_base) + k) * 2;
                 cxy[o] = w_xy[w][2 * r];
                 cxy[o + 1] = w_xy[w][2 * r + 1];
+                cpos[static_cast<size_t>(w_rgrid[w].item_base) + r] = static_cast<uint16_t>(k);
             }
         }
         if (ncell) HIP_CHECK(hipMemcpy(d_rcell_off, co.data(), ncell * sizeof(int32_t), hipMemcpyHostToDevice));
         if (nitem) HIP_CHECK(hipMemcpy(d_rcell_items, ci.data(), nitem * sizeof(uint16_t), hipMemcpyHostToDevice));
         if (nitem) HIP_CHECK(hipMemcpy(d_rcell_xy, cxy.data(), nitem * 2 * sizeof(float), hipMemcpyHostToDevice));
+        if (nitem) HIP_CHECK(hipMemcpy(d_rcell_pos, cpos.data(), nitem * sizeof(uint16_t), hipMemcpyHostToDevice));
         d.rcell_xy = static_cast<const float2 *>(d_rcell_xy);
+        d.rcell_pos = static_cast<const uint16_t *>(d_rcell_pos);
         HIP_CHECK(hipMemcpy(const_cast<gd::GridHdr *>(d.rgrid), w_rgrid.data(), sizeof(gd::GridHdr) * W, hipMemcpyHostToDevice));
         d.rcell_off = static_cast<const int32_t *>(d_rcell_off);
         d.rcell_items = static_cast<const uint16_t *>(d_rcell_items);

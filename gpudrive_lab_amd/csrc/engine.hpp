@@ -111,6 +111,7 @@ struct DevSim {
     const int32_t *rcell_off;      // per world nx*ny+1 entries, local offsets
     const uint16_t *rcell_items;   // local road indices
     const float2 *rcell_xy;        // the (x, y) of those roads, in the same (cell-sorted) order: one coalesced stream per grid row
+    const uint16_t *rcell_pos;     // [roads] the inverse: where road r of its world sits in the world's cell-sorted order (set order IS that order)
     float4 *knn_prev;              // [W][A] {x, y, K-th key of the previous selection or +inf, 0}
     // linear road selection (map_obs_linear.hip): workgroups of 4 waves x lin_apw agent slots, (world << 8 | group) or -1 (filler),
     // ordered so that every workgroup of a world has the same index modulo 8 (= runs on the same XCD)

@@ -853,8 +853,8 @@ __global__ __launch_bounds__(64) void k_map_obs(DevSim d) {
 // ---- set-order mode (gd_config.knn_order = GD_KNN_SET_ORDER) ----
 //
 // Same row SET as the reference (the K nearest by (distance^2, road index), then the radius filter), rows in the order
-// the candidates are gathered in (grid cell by grid cell, ascending road index inside a cell; the full-stream path:
-// ascending road index) instead of the reference's heap-history order.  Because the radius filter runs after the
+// of the world's cell-sorted road list (grid cell by grid cell, ascending road index inside a cell: what the gather yields;
+// the full-stream path re-orders its selection into it, SetSel::to_cell_order) instead of the reference's heap-history order.  Because the radius filter runs after the
 // top-K, the result is "every in-radius road" whenever fewer than K roads are in radius, and the K smallest of the
 // in-radius roads otherwise; no heap is needed.  Each wave takes its agents one at a time, all 64 lanes cooperating:
 //
@@ -951,6 +951,55 @@ struct SetSel {
             kth = __uint_as_float(lo);
         }
         return count;
+    }
+
+    // The selection above lists its roads in ascending road index; the mode's row order is the order of the world's
+    // cell-sorted road list (what the grid gather of k_map_obs_set yields: grid cell by grid cell, ascending road index inside a
+    // cell).  An agent takes the full-stream path after every reset and the grid path on the steps that follow: both must
+    // give ONE order, or a consumer that flattens the rows sees them permuted from one step to the next.  out[0..count) is
+    // re-ordered by each road's position in that list (engine.hpp rcell_pos): the positions are marked in a bitmap of the
+    // world's roads, and a road's new slot is the number of marked positions below its own.  `words`: GD_MAX_ROAD_ENTITIES / 32
+    // + 1 words of LDS, `tmp`: K entries.
+    static __device__ __attribute__((noinline)) void to_cell_order(const uint16_t *pos_of, unsigned short *out, int count, unsigned int *words,
+                                                         unsigned short *tmp, int lane) {
+        constexpr int NWORD = (GD_MAX_ROAD_ENTITIES + 31) / 32, PER = (NWORD + 63) / 64;
+        for (int q = lane; q < NWORD; q += 64) words[q] = 0u;
+        wave_sync();
+        constexpr int NP = (K + 63) / 64;
+        unsigned int road[NP], pos[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int j = p * 64 + lane;
+            road[p] = j < count ? out[j] : 0u;
+            pos[p] = pos_of[road[p]];
+        }
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            if (p * 64 + lane < count) atomicOr(&words[pos[p] >> 5], 1u << (pos[p] & 31u));
+        wave_sync();
+        // marked positions below each lane's PER consecutive words (exclusive scan over the lanes)
+        int own = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) own += lane * PER + k < NWORD ? __popc(words[lane * PER + k]) : 0;
+        int incl = own;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+        const int excl = incl - own;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {  // (every lane runs this: the shuffle reads lanes that hold no road of their own)
+            const int wd = (int)(pos[p] >> 5), owner = wd / PER;
+            int below = __shfl(excl, owner);
+            for (int k = owner * PER; k < wd; k++) below += __popc(words[k]);
+            below += __popc(words[wd] & ((1u << (pos[p] & 31u)) - 1u));
+            if (p * 64 + lane < count) tmp[below] = (unsigned short)road[p];
+        }
+        wave_sync();
+        for (int j = lane; j < count; j += 64) out[j] = tmp[j];
+        wave_sync();
     }
 };
 
@@ -1363,7 +1412,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GD_SET_
                 SET_PHASE(4);
             }
         }
-        if (!done) count = S::select_streaming(d, rxy, R, knn, ex, ey, iw, iz, ckey, cidx, out, lane, kth);
+        if (!done) {
+            count = min(S::select_streaming(d, rxy, R, knn, ex, ey, iw, iz, ckey, cidx, out, lane, kth), K);
+            // k-NN: into the mode's one row order (the linear scan's order IS ascending road index)
+            if (knn) S::to_cell_order(d.rcell_pos + r0, out, count, reinterpret_cast<unsigned int *>(ckey), cidx, lane);
+        }
         count = min(count, K);
         if (lane == 0) {
             d.knn_prev[i] = make_float4(ex, ey, kth, 0.f);

@@ -290,3 +290,29 @@ def test_rows_left_in_place_are_the_rows_a_rewrite_would_produce(monkeypatch, mo
     assert skip.stat(30) > 0 and plain.stat(30) == 0
     skip.close()
     plain.close()
+
+
+@pytest.mark.parametrize("rows", ["fused", "row_kernel"])
+def test_set_order_is_one_order_on_both_selection_paths(monkeypatch, rows):
+    """Set order promises ONE row order (the world's cell-sorted road list).  An agent's first selection after a reset has only
+    the radius for a bound and, with thousands of roads in reach, takes the full-stream path; the next one is bounded by the
+    first and takes the grid path.  A parked car sees the same roads in the same places on both steps: its rows must be
+    bit-identical, order included (the pose stamps are switched off so that both steps really write them)."""
+    monkeypatch.setenv("GPUDRIVE_NO_POSE_SKIP", "1")
+    if rows == "row_kernel":
+        monkeypatch.setenv("GPUDRIVE_SET_FUSED_ROWS", "0")
+    kw = dict(PPO_DEFAULT, roadObservationAlgorithm=0, polylineReductionThreshold=0.0, observationRadius=100.0)
+    gpu = P.make_gpu_sim([TEST_JSON, SCENE_407], max_agents=64, knn_order=1, **kw)
+    resp = RC.as_np(gpu.response_type_tensor())[..., 0]
+    n = RC.as_np(gpu.shape_tensor())[:, 0]
+    parked = (resp == 2) & (np.arange(64)[None, :] < n[:, None])
+    first = RC.as_np(gpu.agent_roadmap_tensor()).copy()
+    full = (first[..., 6] > 0).sum(-1) == 200
+    assert (parked & full).sum() >= 3, "the scenes should hold parked cars with K roads in reach"
+    for _ in range(3):
+        gpu.step()
+        now = RC.as_np(gpu.agent_roadmap_tensor())
+        assert np.array_equal(now[parked].view(np.uint32), first[parked].view(np.uint32)), "a parked car's rows changed their order"
+    gpu.reset([0, 1])   # the full-stream path again
+    assert np.array_equal(RC.as_np(gpu.agent_roadmap_tensor())[parked].view(np.uint32), first[parked].view(np.uint32))
+    gpu.close()
