@@ -365,7 +365,7 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         elif workload in ("synthetic", "waymo"):
             tkey = ("set_" if knn_order == 1 else "exact_") + workload
         else:  # lidar, bev, rl_loop: collected in the default (reference) row order only
-            tkey = workload if knn_order == 0 else ("set_cfg3" if workload == "cfg3" else None)
+            tkey = workload if knn_order == 0 else ({"cfg3": "set_cfg3", "rl_loop": "rl_loop_set"}.get(workload))
         if agents_override:
             tkey = (tkey or "") + "_128"
         stamp = source_stamp()
@@ -380,6 +380,10 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         traffic = None
     res["roofline"] = dict(bound="hbm", kernel=road_kernel, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                            frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                           traffic_note="(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch, rocprofv3 --pmc passes of this build (profiles/): "
+                                        "FETCH_SIZE is doubled per the gfx950 note of MI355X_MICROARCH.md, which is calibrated for wide "
+                                        "coalesced streams -- it OVER-counts the 8- and 16-byte strided / gathered reads of the rank "
+                                        "replay's scratch rows and of the road records (the guide calls other widths uncalibrated)",
                            algorithmic_bytes_per_launch=alg_bytes, avg_kernel_us=kt[road_kernel]["avg_us"],
                            design_min_bytes_per_launch=design_min,
                            survey_bytes_per_launch=survey_bytes, reference_bytes_per_launch=reference_bytes,
@@ -425,10 +429,12 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     res["overlapped_kernels"] = overlapped
     res["engine"] = dict(graph_steps=sim.stat(0), plain_steps=sim.stat(1), graph_captures=sim.stat(2),
                          set_order_rows_fused=sim.stat(3), set_order_agents_per_wave=sim.stat(4),
-                         road_kernel_agents_per_wave=sim.stat(6),
+                         road_kernel_agents_per_wave=sim.stat(6), rank_audit_violations=sim.stat(21),
                          schedule_env={k: os.environ[k] for k in ("GPUDRIVE_NO_GRAPH", "GPUDRIVE_SET_FUSED_ROWS",
                                                                    "GPUDRIVE_SET_AGENTS_PER_WAVE") if k in os.environ})
     # ---- BASELINE configs[3]: observation all-gather over RCCL, overlapped with the next step ----
+    if res["engine"]["rank_audit_violations"] != 0:  # an index of the rank path left its array (clamped on the device): no number of this run counts
+        raise SystemExit("bench.py: %s: the rank path's bounds audit counted %d violations (gd_stat 21)" % (name, res["engine"]["rank_audit_violations"]))
     if world > 1 and args.gather != "none" and name == args.workloads.split(",")[0]:
         res["allgather"] = gather_stretch(sim, batches, all_worlds, args, k, device, world)
     sim.close()
@@ -439,40 +445,68 @@ def gather_stretch(sim, batches, all_worlds, args, k, device, world):
     """Every step: simulator step, fused observation pack, all-gather of the packed block (raw) or of the controlled
     agents' rows (compact) on a side stream while the next step runs (sharding.ObservationGather)."""
     import torch.distributed as dist
-    D = 6 + (args.agents - 1) * 6 + 200 * 13
-    og = sharding.ObservationGather(args.gather, args.worlds * args.agents, D, device, timing=True)
-    og.set_mask(sim.controlled_state_tensor().to_torch()[..., 0] == 1)
+    ctrl = sim.controlled_state_tensor().to_torch()[..., 0] == 1
+    if args.gather_payload == "packed":
+        D = 6 + (args.agents - 1) * 6 + 200 * 13
+        parts = [(sharding.ObservationGather(args.gather, args.worlds * args.agents, D, device, timing=True), sim.packed_observations)]
+    else:  # raw_rows: the exported rows themselves, three gathers per step (no concatenation pass), a quarter fewer bytes
+        parts = [(sharding.ObservationGather(args.gather, args.worlds * args.agents, dim, device, timing=True), getter) for dim, getter in (
+            (8, lambda: sim.self_observation_tensor().to_torch()),
+            ((args.agents - 1) * 9, lambda: sim.partner_observations_tensor().to_torch()),
+            (200 * 9, lambda: sim.agent_roadmap_tensor().to_torch()))]
+    for g, _ in parts:
+        g.set_mask(ctrl)
+    og = parts[-1][0]
     act = sim.action_tensor().to_torch()
     steps = args.gather_steps
 
     def one(i):
         act.copy_(batches[i % len(batches)])
         sim.step()
-        obs = sim.packed_observations()
+        blocks = [getter() for _, getter in parts]
         if i > k:
-            og.wait()          # the learner would consume step i-1's gathered block here
-        og.start(obs)
+            for g, _ in parts:
+                g.wait()       # the learner would consume step i-1's gathered blocks here
+        for (g, _), blk in zip(parts, blocks):
+            g.start(blk)
     for i in range(k, k + 3):
         one(i)
-    og.wait()
-    og.events.clear()
+    for g, _ in parts:
+        g.wait()
+        g.events.clear()
     sharding.barrier(device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for i in range(k + 3, k + 3 + steps):
         one(i)
-    full, counts = og.wait()
+    for g, _ in parts:
+        full, counts = g.wait()
     torch.cuda.synchronize(device)
     sharding.barrier(device)
     elapsed = sharding.reduce_max(time.perf_counter() - t0, device)
-    ms = og.mean_ms()
-    per_rank = og.bytes_per_rank
-    return dict(mode=args.gather, backend=dist.get_backend(), world_size=dist.get_world_size(), steps=steps,
+    ms = sum(g.mean_ms() or 0.0 for g, _ in parts)
+    per_rank = sum(g.bytes_per_rank for g, _ in parts)
+    share = float(ctrl.float().mean().item())
+    return dict(mode=args.gather, payload=args.gather_payload, bytes_per_rank_by_payload_and_mode=gather_bytes_table(args.worlds, args.agents, share),
+                backend=dist.get_backend(), world_size=dist.get_world_size(), steps=steps,
                 bytes_per_rank=per_rank, rows_per_rank=int(og.cap), controlled_per_rank=[int(c) for c in counts.tolist()],
                 allgather_ms=ms, ms_per_step_with_gather=1e3 * elapsed / steps,
                 gb_per_s_per_link=(per_rank / (ms * 1e-3) / 1e9) if ms else None,
                 gathered_shape=list(full.shape),
                 note="per-link rate = one peer's block / gather time (every peer's block rides its own xGMI link)")
+
+
+def gather_bytes_table(worlds, agents, controlled_share=None):
+    """Bytes one rank contributes to config 4's all-gather per step, by payload and mode: `packed` = the learner's normalised
+    row (6 + (A - 1) * 6 + 200 * 13 floats per agent slot), `raw_rows` = the exported rows it is made of (self 8 + partner
+    (A - 1) * 9 + road 200 * 9 floats: a quarter fewer floats than the one-hot packed form; the learner then normalises after the
+    gather); `raw` = every agent slot, `compact` = controlled agents only (share given, else left symbolic as bytes per agent)."""
+    per_agent = {"packed": 4 * (6 + (agents - 1) * 6 + 200 * 13), "raw_rows": 4 * (8 + (agents - 1) * 9 + 200 * 9)}
+    out = {}
+    for payload, b in per_agent.items():
+        out[payload] = dict(bytes_per_agent=b, raw=b * worlds * agents,
+                            compact=(int(b * worlds * agents * controlled_share) if controlled_share is not None else None))
+    return out
 
 
 def cpu_baseline(args, budget_s=15.0):
@@ -545,6 +579,9 @@ def main():
     ap.add_argument("--gather", default="compact", choices=("none", "raw", "compact"),
                     help="N > 1 only: after the timed region, a stretch with the observation all-gather of BASELINE configs[3] "
                          "(raw = every agent slot's packed observation, compact = controlled agents only), overlapped with the next step")
+    ap.add_argument("--gather-payload", default="packed", choices=("packed", "raw_rows"),
+                    help="what the all-gather stretch sends: the packed, normalised observation (6 + (A - 1) * 6 + 200 * 13 floats per "
+                         "agent) or the exported self / partner / road rows it is made of (8 + (A - 1) * 9 + 200 * 9 floats: a quarter fewer bytes)")
     ap.add_argument("--gather-steps", type=int, default=30)
     ap.add_argument("--workloads", default="synthetic,waymo,cfg3,lidar,bev,rl_loop,synthetic_128,waymo_raw,synthetic_set,waymo_set,cfg3_set,"
                                             "synthetic_linear,waymo_linear,ppo_default,rl_loop_set",
@@ -564,6 +601,7 @@ def main():
                     help="no GPU work: every rank joins the process group, the ranks are counted with one all-reduce and rank 0 "
                          "prints a line with `distributed` filled in (checks the launch path, e.g. on a CPU-only box with "
                          "--dist-backend gloo)")
+    ap.add_argument("--dry-run-sleep", type=float, default=0.0, help="--dry-run only: every rank sleeps this long before it leaves (tests of the launch path's signal handling)")
     ap.add_argument("--headless", action="store_true",
                     help="also print the reference CLI's two lines (src/headless.cpp:145-155) for the primary workload on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -579,14 +617,35 @@ def main():
     # process that has initialised HIP must never be replaced or forked.  The children print rank 0's JSON line on our
     # stdout; our exit code is theirs.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        import socket
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
+        # --standalone: the launcher picks its own free rendezvous port (no bind-then-close window in which another process can
+        # take it); --local-addr: the container's hostname may not resolve.  The children get a session of their own so that a
+        # signal that ends this process (a `timeout` around it, Ctrl-C) ends every rank with it instead of leaving them on the
+        # GPUs; our exit code is theirs.
+        import signal
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--standalone", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
         sys.stderr.write("bench.py: --gpus %d without a launcher: spawning %s\n" % (args.gpus, " ".join(cmd[1:9])))
-        raise SystemExit(subprocess.call(cmd))
+        child = subprocess.Popen(cmd, start_new_session=True)
+
+        def end_children(signum=None, frame=None):
+            if child.poll() is None:
+                try:
+                    os.killpg(child.pid, signal.SIGTERM)
+                    try:
+                        child.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        os.killpg(child.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+            if signum is not None:
+                raise SystemExit(128 + signum)
+        for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            signal.signal(sig, end_children)
+        try:
+            rc = child.wait()
+        finally:
+            end_children()
+        raise SystemExit(rc)
 
     if args.dry_run:
         rank, local_rank, world = sharding.init_process_group(backend=args.dist_backend or "gloo")
@@ -594,10 +653,31 @@ def main():
             raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
         import torch.distributed as dist
         seen = torch.ones(1)
+        gather = None
         if dist.is_initialized():
             dist.all_reduce(seen)
+            # one round of config 4's observation gather on host tensors of the real row shape (2 worlds per rank), both modes:
+            # rank r's rows must land in section r on every rank
+            W, A = 2, args.agents
+            D = 6 + (A - 1) * 6 + 200 * 13
+            g = torch.Generator().manual_seed(7 + rank)
+            block = torch.full((W, A, D), float(rank))
+            ctrl = torch.rand(W, A, generator=g) < 0.25 + 0.05 * rank   # unequal controlled counts
+            ok = True
+            for mode in ("raw", "compact"):
+                og = sharding.ObservationGather(mode, W * A, D, torch.device("cpu"))
+                og.set_mask(ctrl)
+                og.start(block)
+                full, counts = og.wait()
+                for r in range(world):
+                    n = int(counts[r])
+                    ok = ok and n > 0 and bool((full[r * og.cap:r * og.cap + n] == float(r)).all())
+            gather = dict(ok=bool(ok), rows_per_rank_compact=int(og.cap), controlled_per_rank=[int(c) for c in og.counts.tolist()])
+            if args.dry_run_sleep > 0:
+                time.sleep(args.dry_run_sleep)
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_counted": int(seen.item()),
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_counted": int(seen.item()), "gather_round": gather,
+                              "gather_bytes_per_rank": gather_bytes_table(args.worlds, args.agents),
                               "distributed": dict(world_size=dist.get_world_size(), backend=dist.get_backend())
                               if dist.is_initialized() else None}), flush=True)
         if dist.is_initialized():

@@ -146,6 +146,12 @@ struct gd_sim {
         const size_t WA = static_cast<size_t>(W) * A;
         const size_t first = internal.size();
         try {
+            // developer switch for the test of the path below: the device "runs out of memory" in the middle of the allocations
+            if (std::getenv("GPUDRIVE_RANK_ALLOC_FAIL") != nullptr) {
+                d.rk_E = alloc_internal<uint16_t>(WA * GD_RANK_CAP + 64);
+                d.rk_spc = alloc_internal<uint16_t>(WA * GD_RANK_SPL);
+                throw HipError("GPUDRIVE_RANK_ALLOC_FAIL: simulated allocation failure of the rank replay's buffers");
+            }
             d.rk_E = alloc_internal<uint16_t>(WA * GD_RANK_CAP + 64);  // the replay prefetches up to 24 entries past a row
             d.rk_spc = alloc_internal<uint16_t>(WA * GD_RANK_SPL);
             d.rk_kt = alloc_internal<float>(WA * GD_RANK_KT);
@@ -176,6 +182,11 @@ struct gd_sim {
             rk_possible = false;
             d.rk_on = 0;
             d.rk_nlong = 0;
+            // nothing may point at what was just returned
+            d.rk_E = nullptr; d.rk_spc = nullptr; d.rk_kt = nullptr; d.rk_heap = nullptr; d.rk_cpe = nullptr; d.rk_n = nullptr;
+            d.rk_fallback = nullptr; d.rk_streak = nullptr; d.cp_road = nullptr; d.cp_T = nullptr; d.cp_hdr = nullptr;
+            d.rk_words = nullptr; d.rk_tl = nullptr; d.rk_hist = nullptr; d.rk_ticket = nullptr; d.rk_order = nullptr;
+            d.rk_list = nullptr; d.rk_longlist = nullptr; d.rk_longslot = nullptr; d.rk_E_long = nullptr; d.rk_kt_long = nullptr;
             return false;
         }
         rk_alloc = true;
@@ -684,10 +695,9 @@ struct gd_sim {
             for (int w = 0; w < W; w++) groups += (w_agents[w] + 31) / 32;
             const char *pin = std::getenv("GPUDRIVE_RANK_MIN_ROADS");
             d.rk_min_roads = pin ? std::atoi(pin) : (groups >= 4 * cu_count ? GD_MAP_OBS_K : 1536);
-            // and not the largest worlds: with 200 ln(R / 200) inserts per agent and the superset on top, unreduced Waymo
-            // scenes (5-10 thousand roads) overflow the 1280-candidate buffer for one agent in eight, which sends every group
-            // of 32 to the fallback (measured: 3.80 ms ranked + fallback against 3.39 on keys alone).  Groups that keep
-            // overflowing below this size bypass the rank kernels on their own (rk_streak).
+            // Worlds of every size take it since round 4 (agents whose candidates overflow the standard ranking's 1272 go to the
+            // long-list instantiation, 2552; groups that keep overflowing even that bypass the rank kernels on their own:
+            // rk_streak).  GPUDRIVE_RANK_MAX_ROADS pins an upper limit for experiments.
             const char *pin_max = std::getenv("GPUDRIVE_RANK_MAX_ROADS");
             d.rk_max_roads = pin_max ? std::atoi(pin_max) : GD_MAX_ROAD_ENTITIES;
             d.rk_on = 0;
@@ -841,8 +851,8 @@ struct gd_sim {
         HIP_CHECK(hipMemcpy(d.knn_prev, prev.data(), prev.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 
-    // No checkpoint of a previous selection survives a change of the worlds' roads or agent slots: the next selection of
-    // every agent takes the fallback, which records fresh ones.
+    // No checkpoint of a previous selection survives a change of the worlds' roads or agent slots: in its next selection
+    // every agent is bounded afresh inside k_knn_scan (a distance histogram at geometric road counts, map_obs_rank.hip).
     void reset_rank_state() {
         HIP_CHECK(hipMemset(d.cp_hdr, 0, sizeof(float4) * 2 * static_cast<size_t>(W) * A));
         HIP_CHECK(hipMemset(d.rk_fallback, 0, sizeof(int32_t) * (static_cast<size_t>(W) * A / 32)));

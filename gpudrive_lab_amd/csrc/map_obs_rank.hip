@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
     __shared__ unsigned short s_first[NCP][64];  // checkpoint q of lane l: first road it holds for ...
     __shared__ float s_thr[NCP][64];             // ... and the scan threshold it gives
     __shared__ int s_ncp[64];                    // checkpoints of lane l; 0: the lane takes no part in the scan
+    __shared__ unsigned int s_needy[2];          // the agents to be bounded afresh (bit per lane), as the first wave saw them
     // (40 KB in all: four workgroups per CU, i.e. every workgroup of a 1024-world launch resident at once -- with 46 KB, three
     // per CU and a second generation, the kernel took 91 us instead of 61.  What only the set-up before the scan loop needs
     // therefore lives in the buffers of the loop: the transpose buffer and the road tile)
@@ -291,6 +292,12 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
             if (state == RK_FAR) ncp = 0;
         }
         s_ncp[lane] = ncp;
+        {
+            // published once, before the barrier: the waves below must all see ONE mask (a wave that finishes an agent rewrites
+            // its s_ncp entry, and a late reader of s_ncp would deal the turns differently and skip the barrier behind the loop)
+            const unsigned long long nd = __ballot(ncp < 0);
+            if (lane == 0) { s_needy[0] = (unsigned int)nd; s_needy[1] = (unsigned int)(nd >> 32); }
+        }
         if (ncp < 0) ncp = 1;  // (bounded afresh below: on the rank path like the others)
         // the agents on the rank path, as a list: k_knn_rank's waves share THEM out, not the live agents (on the Waymo tiles
         // five agents in six are parked out of reach of every road, and a wave that drew three of the others set the pace).
@@ -306,8 +313,8 @@ __global__ __launch_bounds__(256) void k_knn_scan(DevSim d) {
     // K-th smallest distance so far is a bound of the K-th distance from there on -- a checkpoint like those a previous
     // selection leaves, at most 4.4 % loose, made without one.  About 6 us per such agent. ----
     {
-        const unsigned long long needy = __ballot(s_ncp[lane] < 0);
-        if (needy != 0ull) {
+        const unsigned long long needy = (unsigned long long)s_needy[0] | (unsigned long long)s_needy[1] << 32;
+        if (needy != 0ull) {  // (workgroup-uniform)
             constexpr int BASE = (127 - 2) << 4;  // bucket 0: below 2^-2 m^2; bucket 255: 2^13.9 m^2 (118 m) and beyond = unbounded
             unsigned int *hist = s_hist[wave];
             int turn = 0;

@@ -316,3 +316,22 @@ def test_set_order_is_one_order_on_both_selection_paths(monkeypatch, rows):
     gpu.reset([0, 1])   # the full-stream path again
     assert np.array_equal(RC.as_np(gpu.agent_roadmap_tensor())[parked].view(np.uint32), first[parked].view(np.uint32))
     gpu.close()
+
+
+def test_rank_buffers_that_cannot_be_allocated_leave_the_batch_on_the_history_replay(oracle_mod, bench_scenes, monkeypatch):
+    """engine.cpp ensure_rank_buffers: when the device cannot give the rank replay its scratch (simulated: the third allocation
+    throws), what was allocated is returned, nothing points at it any more, the batch is selected by k_map_obs -- the same
+    rows -- and the rank replay is not tried again for this simulator, through a rebuild too."""
+    monkeypatch.setenv("GPUDRIVE_RANK_ALLOC_FAIL", "1")
+    scenes = bench_scenes[:2]
+    kw = dict(BENCH_LINEAR, roadObservationAlgorithm=0)
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    assert gpu.stat(7) == 0, "the rank replay must be off after the failed allocation"
+    P.compare_fresh(gpu, orc)
+    P.lockstep(gpu, orc, 3, 0, seed=1)
+    gpu.set_maps(scenes[::-1])
+    orc.set_maps(scenes[::-1])
+    assert gpu.stat(7) == 0 and gpu.stat(21) == 0
+    P.compare_fresh(gpu, orc)
+    gpu.close()

@@ -12,43 +12,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 TAGS = ("exact_synthetic", "exact_waymo", "set_synthetic", "set_waymo", "lidar", "cfg3", "set_cfg3", "bev", "rl_loop",
-        "exact_synthetic_128", "waymo_raw")
+        "exact_synthetic_128", "waymo_raw", "synthetic_linear", "waymo_linear", "ppo_default", "rl_loop_set")
 
 
 def stamp():
     os.environ.setdefault("GPUDRIVE_MAX_AGENTS", "64")
     import bench
     return bench.source_stamp()
-
-
-def occupancy_of(trace_dir):
-    """Per kernel: registers, LDS and workgroup shape from the newest kernel trace, and the waves per SIMD they allow
-    (VGPR granule 8, 512 per SIMD; LDS 160 KiB per CU shared by 4 SIMDs; hardware cap 8)."""
-    import csv
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
-    occ = {}
-    if not files:
-        return occ
-    for row in csv.DictReader(open(files[-1])):
-        m = re.search(r"(k_[a-z_]+(<[^>]*>)?)", row.get("Kernel_Name", ""))
-        if not m or m.group(1) in occ:
-            continue
-        g = lambda k: int(float(row.get(k, 0) or 0))
-        vg, lds = g("VGPR_Count") + g("Accum_VGPR_Count"), g("LDS_Block_Size")
-        wg = max(1, g("Workgroup_Size_X")) * max(1, g("Workgroup_Size_Y")) * max(1, g("Workgroup_Size_Z"))
-        grid = max(1, g("Grid_Size_X")) * max(1, g("Grid_Size_Y")) * max(1, g("Grid_Size_Z"))
-        waves_wg = (wg + 63) // 64
-        alloc = -(-max(vg, 1) // 8) * 8
-        by_vgpr = min(8, 512 // alloc)
-        by_lds = min(8.0, (160 * 1024 // lds) * waves_wg / 4.0) if lds else 8.0
-        occ[m.group(1)] = dict(vgpr=g("VGPR_Count"), agpr=g("Accum_VGPR_Count"), sgpr=g("SGPR_Count"), lds_bytes_per_workgroup=lds,
-                               workgroup_size=wg, workgroups=grid // wg, waves_per_simd_by_vgpr=by_vgpr,
-                               waves_per_simd_by_lds=by_lds, waves_per_simd=min(8.0, by_vgpr, by_lds))
-    return occ
 
 
 traffic = {"source_stamp": stamp()}
@@ -66,8 +38,8 @@ for tag in TAGS:
     for name in ("pmc_traffic_summary.json", "pmc_sq_summary.json", "kernel_work_summary.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), dst + name.replace("_summary", ""))
-    with open(dst + "occupancy.json", "w") as fh:
-        json.dump(occupancy_of(os.path.join(src, "trace")), fh, indent=1)
+    # (registers / spills / waves per SIMD in it come from the compiler: tools/profile_summarize.py wrote it on the GPU box)
+    shutil.copy(os.path.join(src, "occupancy.json"), dst + "occupancy.json")
     with open(os.path.join(src, "pmc_traffic_summary.json")) as fh:
         pmc = json.load(fh)
     # how often a kernel's launch does work at all (the trace run: k_map_obs is launched every step but selects only for the

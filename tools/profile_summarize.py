@@ -24,7 +24,19 @@ with open(out+"/kernel_stats_summary.csv","w") as fh:
         w=csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 for r in rows[:8]:
     print({k:(v[:64] if isinstance(v,str) else v) for k,v in r.items() if k in ("Name","Calls","AverageNs","MinNs","MaxNs","Percentage")})
-# occupancy facts per kernel from the kernel trace
+# occupancy facts per kernel: launch geometry and LDS from the kernel trace, registers / spills / waves per SIMD from the
+# COMPILER (profiles/rNN_compiler_resources.json, written by `tools/resources.py --json-all` for this source stamp).
+# rocprofv3's VGPR_Count is half the allocation on gfx950 (k_world_step: 48 reported, 95 allocated): rounds 2-4 took it at
+# face value and reported eight waves per SIMD where the compiler says five.
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+comp={}
+for f in sorted(glob.glob(os.path.join(ROOT,"profiles","r*_compiler_resources.json")), reverse=True):
+    comp=json.load(open(f)); comp["file"]=os.path.basename(f); break
+def compiler_row(n):
+    norm=lambda x: re.sub(r"\s+","",x)
+    for k,r in comp.get("kernels",{}).items():
+        if norm(k)==norm(n): return r
+    return None
 occ={}
 for f in newest(out+"/trace/**/*kernel_trace.csv"):
     for row in csv.DictReader(open(f)):
@@ -37,9 +49,20 @@ for f in newest(out+"/trace/**/*kernel_trace.csv"):
         alloc=-(-max(vg,1)//8)*8
         by_vgpr=min(8,512//alloc)
         by_lds=(160*1024//lds)*waves_wg/4.0 if lds else 8
-        occ[n]=dict(vgpr=g("VGPR_Count"),agpr=g("Accum_VGPR_Count"),sgpr=g("SGPR_Count"),lds_bytes_per_workgroup=lds,workgroup_size=wg,
-                    grid_size=max(1,g("Grid_Size_X"))*max(1,g("Grid_Size_Y"))*max(1,g("Grid_Size_Z")),waves_per_simd_by_vgpr=by_vgpr,waves_per_simd_by_lds=min(8,by_lds),
-                    waves_per_simd=min(8,by_vgpr,by_lds))
+        c=compiler_row(n)
+        if c:
+            by_vgpr=c["waves_per_simd"]
+            occ[n]=dict(vgpr=c["vgpr"],agpr=c["agpr"],sgpr=c["sgpr"],vgpr_spills=c["vgpr_spills"],sgpr_spills=c["sgpr_spills"],
+                        registers_from="compiler (%s, source stamp %s)" % (comp.get("file"), comp.get("source_stamp")),
+                        rocprofv3_vgpr_count=g("VGPR_Count"))
+        else:
+            occ[n]=dict(vgpr=None,agpr=None,sgpr=g("SGPR_Count"),registers_from="no compiler record for this kernel; rocprofv3's VGPR_Count "
+                        "(half the allocation on gfx950) is %d" % g("VGPR_Count"),rocprofv3_vgpr_count=g("VGPR_Count"))
+            by_vgpr=min(8,512//(-(-max(2*vg,1)//8)*8))
+        grid=max(1,g("Grid_Size_X"))*max(1,g("Grid_Size_Y"))*max(1,g("Grid_Size_Z"))
+        occ[n].update(lds_bytes_per_workgroup=lds,workgroup_size=wg,grid_size=grid,waves_per_simd_by_registers=by_vgpr,
+                      waves_per_simd_by_lds=min(8,by_lds),waves_per_simd=min(8,by_vgpr,by_lds),
+                      waves_per_simd_the_grid_provides=round(grid/64.0/1024.0,2))
 json.dump(occ, open(out+"/occupancy.json","w"), indent=1)
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in newest(out+"/pmc_*/**/*counter_collection.csv"):
