@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """developer tool: DESIGN.md section 6's results table (between the `<!-- results table -->` markers) from the committed bench
-lines: profiles/r04_bench_driver_command.json (first figure of each cell), profiles/r04_bench_default.json (in brackets) and
-profiles/r03_bench_driver_command.json (the round-3 column)."""
-import json, os
+lines: profiles/r05_bench_driver_command.json and, for the last column, profiles/r04_bench_driver_command.json."""
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -14,41 +13,42 @@ def load(f):
     return out, d
 
 
-A, lineA = load("r04_bench_driver_command.json")
-B, _ = load("r04_bench_default.json")
-C, _ = load("r03_bench_driver_command.json")
-# not in round 3's line: timed this round on the build the round began with (gpurun_out of the first bench call)
-EARLY = {"synthetic_128": "← 3.28 ms (this round's first build)", "waymo_raw": "← 3.65 ms (this round's first build)"}
-ROWS = [("synthetic exact-64, R = 4096 (primary)", "synthetic", "reference order"),
-        ("Waymo tiles (35,489 live agents, 6.5 K with roads in reach)", "waymo", "reference order"),
-        ("Waymo tiles, 4096 worlds, AgentStop + goal reward (config 3)", "cfg3", "reference order"),
+A, lineA = load(sys.argv[1] if len(sys.argv) > 1 else "r05_bench_driver_command.json")
+C, _ = load("r04_bench_driver_command.json")
+ROWS = [("synthetic exact-64, R = 4096 (**primary**)", "synthetic", "k-NN, reference order"),
+        ("same scenes", "synthetic_linear", "linear (callers' default)"),
+        ("same scenes", "synthetic_set", "k-NN, set order"),
+        ("same scenes, learner loop", "rl_loop", "reference order + second-pass pack"),
+        ("same scenes, learner loop", "rl_loop_set", "set order + direct pack"),
+        ("same generator, 128 slots, all live", "synthetic_128", "k-NN, reference order"),
+        ("Waymo tiles (35,489 live agents)", "waymo", "k-NN, reference order"),
+        ("Waymo tiles", "waymo_linear", "linear"),
+        ("Waymo tiles", "waymo_set", "k-NN, set order"),
+        ("`ppo_default`: Waymo tiles, 128 slots, `all_non_trivial`, vehicles only", "ppo_default", "linear"),
+        ("config 3: 4096 worlds, AgentStop + goal reward", "cfg3", "k-NN, reference order"),
+        ("config 3", "cfg3_set", "k-NN, set order"),
         ("Waymo tiles + 360° LiDAR (config 5)", "lidar", "reference order"),
         ("Waymo tiles + BEV rasters", "bev", "reference order"),
-        ("synthetic, learner-side loop (`rl_loop`)", "rl_loop", "reference order"),
-        ("synthetic, 128 agent slots (the fork's `kMaxAgentCount`), all live", "synthetic_128", "reference order"),
-        ("Waymo tiles, unreduced polylines (5,191–10,000 roads per world)", "waymo_raw", "reference order"),
-        ("synthetic", "synthetic_set", "set order"), ("Waymo tiles", "waymo_set", "set order"), ("config 3", "cfg3_set", "set order")]
-out = ["| workload | mode | ms/step | events | Σ kernels | live agent-steps/s | road observation | roofline frac | round 3 |", "|---|---|---|---|---|---|---|---|---|"]
+        ("Waymo tiles, unreduced polylines", "waymo_raw", "k-NN, reference order")]
+out = ["| scenes | road selection | ms/step | live agent-steps/s | `k_world_step` µs | road observation µs | frac (bytes moved) | of the reference's bytes | agents left in place / step | round 4 ms/step |",
+       "|---|---|---|---|---|---|---|---|---|---|"]
 for name, key, mode in ROWS:
-    a, b, c = A[key], B[key], C.get(key)
-    nd = 3 if a["ms_per_step"] < 0.2 else 2
-    f = lambda x: ("%%.%df" % nd) % x
-    road = a["kernels"]["k_map_obs+k_map_rows"]["avg_us"] / 1e3
-    extra = ""
-    if key == "lidar":
-        extra = " + `k_lidar` %.2f" % (a["kernels"]["k_lidar"]["avg_us"] / 1e3)
-    if key == "bev":
-        extra = " + `k_bev` %.2f" % (a["kernels"]["k_bev"]["avg_us"] / 1e3)
-    rate = lambda r: "%.0f M" % (r["agent_steps_per_s"] / 1e6) if r["agent_steps_per_s"] >= 1e8 else "%.1f M" % (r["agent_steps_per_s"] / 1e6)
-    prev = "← %s ms, %s, %.1f %%" % (f(c["ms_per_step"]), rate(c), 100 * c["roofline"]["frac"]) if c else EARLY.get(key, "")
+    if key not in A:
+        continue
+    a, c = A[key], C.get(key)
+    rf = a["roofline"]
+    road = [v["avg_us"] for k, v in a["kernels"].items() if k.startswith("k_map_obs")][0]
+    extra = "".join(" + `%s` %.0f" % (k, a["kernels"][k]["avg_us"]) for k in ("k_lidar", "k_bev") if k in a["kernels"])
+    rate = "%.0f M" % (a["agent_steps_per_s"] / 1e6) if a["agent_steps_per_s"] >= 1e8 else "%.1f M" % (a["agent_steps_per_s"] / 1e6)
     bold = "**%s**" if key == "synthetic" else "%s"
-    out.append("| %s | %s | %s (%s) | %s (%s) | %s%s | %s (%s) | %s ms%s | %.1f %% | %s |" % (
-        name, mode, bold % f(a["ms_per_step"]), f(b["ms_per_step"]), f(a["ms_per_step_events"]), f(b["ms_per_step_events"]),
-        f(a["kernels_sum_us"] / 1e3), " + `k_pack_obs`, `k_episode_step`" if key == "rl_loop" else "", bold % rate(a), rate(b),
-        ("%.3f" if road < 0.1 else "%.2f") % road, extra, 100 * a["roofline"]["frac"], prev))
-cpu = lineA["cpu_baseline"]
-out.append("| synthetic, CPU port, %d threads / all %d / 1 thread | — | — | — | — | %.3f M / %.3f M / %.3f M | — | — | |" % (
-    cpu["cores"], cpu["host_cores"], cpu["value"] / 1e6, (cpu["all_cores_value"] or 0) / 1e6, cpu["single_thread_value"] / 1e6))
+    out.append("| %s | %s | %s | %s | %.0f | %.0f%s | %.1f %% | %.0f %% | %.0f of %d | %s |" % (
+        name, mode, bold % ("%.3f" % a["ms_per_step"]), bold % rate, a["kernels"]["k_world_step"]["avg_us"], road, extra, 100 * rf["frac"],
+        100 * rf.get("frac_of_reference_bytes", rf["frac"]), rf.get("agents_skipped_per_launch", 0), a["live_agents_per_rank"],
+        ("%.3f" % c["ms_per_step"]) if c else "— (new)"))
+cpu = lineA.get("cpu_baseline")
+if cpu:
+    out.append("| synthetic, CPU port of the reference algorithm, %d threads / all %d / 1 thread | k-NN, reference order | — | %.3f M / %.3f M / %.3f M | | | | | | |" % (
+        cpu["cores"], cpu["host_cores"], cpu["value"] / 1e6, (cpu["all_cores_value"] or 0) / 1e6, cpu["single_thread_value"] / 1e6))
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
 b0, b1 = "<!-- results table -->\n", "<!-- /results table -->\n"
