@@ -235,10 +235,10 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     if workload == "rl_loop":
         from gpudrive_lab_amd.episode import EpisodeTracker
         tracker = EpisodeTracker(sim)
-        # set order (and the linear scan): the packed observation is written where the rows are produced, and the raw partner /
-        # road rows -- which nothing in this loop reads -- are not written at all (gd_attach_packed); the reference's row order
-        # keeps the second pass (k_pack_obs)
-        direct = sim.direct_pack(only=True)
+        # the packed observation is written where the rows are produced, and the raw partner / road rows -- which nothing in this
+        # loop reads -- are not written at all (gd_attach_packed); GPUDRIVE_BENCH_SECOND_PASS=1 keeps rounds 2-4's second pass
+        # over the raw tensors (k_pack_obs)
+        direct = os.environ.get("GPUDRIVE_BENCH_SECOND_PASS") != "1" and sim.direct_pack(only=True)
 
     gc_ms = [0.0]
     spin_steps = [0]

@@ -756,12 +756,13 @@ struct gd_sim {
         if (d.pack) gd::launch_pack_obs(d, stream, d.pack);
     }
 
-    // the packed observation can be written where the rows are produced when the road kernel of this configuration stores the
-    // rows itself: the linear scan, and set order with its fused write-out
+    // the packed observation can be written where the rows are produced by every road path -- the linear scan, set order
+    // (fused write-out), and k_map_rows behind the reference-order selections and the unfused set-order one -- except the
+    // linear scan's legacy path (GPUDRIVE_LINEAR_LEGACY=1, an A/B switch)
     bool direct_pack_supported() const {
         if (params.disableClassicalObs) return false;
         if (params.roadObservationAlgorithm != GD_ROADS_K_NEAREST) return d.lin_on != 0;
-        return d.knn_order == GD_KNN_SET_ORDER && d.set_fused_rows != 0;
+        return true;
     }
 
     // Uniform grid over the (x, y) of ALL roads of world w: cells of at least 16 m, at most 64 x 64 of them; a road
@@ -1180,9 +1181,7 @@ int gd_attach_packed(gd_sim *s, float *out, int64_t out_bytes, int32_t only) {
     if (out && out_bytes < static_cast<int64_t>(s->W) * s->A * D * 4)
         return fail(GD_ERR_INVALID, "gd_attach_packed: output buffer too small");
     if (out && !s->direct_pack_supported())
-        return fail(GD_ERR_UNSUPPORTED, "gd_attach_packed: this configuration's road kernel does not store the rows itself (reference "
-                                        "row order of the k-NN selection, or GPUDRIVE_SET_FUSED_ROWS=0 / GPUDRIVE_LINEAR_LEGACY=1): use "
-                                        "gd_pack_observations");
+        return fail(GD_ERR_UNSUPPORTED, "gd_attach_packed: not available with disableClassicalObs or GPUDRIVE_LINEAR_LEGACY=1: use gd_pack_observations");
     return guarded([&]() {
         HIP_CHECK(hipStreamSynchronize(s->stream));
         s->drop_graph();

@@ -475,15 +475,19 @@ __device__ __forceinline__ void order_waves(const DevSim &d, int count, unsigned
 #ifndef GD_SET_CAP
 #define GD_SET_CAP 1024
 #endif
-constexpr int ROWS_AB = 5;
-template <int A_T>
+// PACK (gd_attach_packed): the same rows also -- or only: DevSim::pack_only -- in the packed observation's 13 normalised columns
+// (pack_cols.hpp), three agents per workgroup instead of five (the 13-column block fills the same LDS).
+template <bool PACK> struct RowsGeo { static constexpr int AB = PACK ? 3 : 5; };
+template <int A_T, bool PACK = false>
 __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
+    constexpr int ROWS_AB = RowsGeo<PACK>::AB;
     constexpr int U = GD_ROWS_PER_THREAD;  // entries per thread (256 apart): independent load chains in flight
     constexpr int RB = ROWS_AB * K;        // rows per workgroup
-    static_assert(256 * U >= RB && (RB * 9) % 4 == 0 && (K * 9) % 4 == 0, "every entry has a thread; whole 16-byte pieces per agent");
+    static_assert(256 * U >= RB && (RB * 9) % 4 == 0 && (K * 9) % 4 == 0 && (K * 13) % 4 == 0, "every entry has a thread; whole 16-byte pieces per agent");
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
-    __shared__ __attribute__((aligned(16))) float s_rows[RB * 9];
+    __shared__ __attribute__((aligned(16))) float s_rows[RB * (PACK ? 13 : 9)];
     static_assert(RB * 9 >= 513, "order_waves borrows the row buffer");
+    static_assert(!PACK || 3 * K * 13 * 4 <= 5 * K * 9 * 4, "the packed block fits the LDS of the raw one");
     if (blockIdx.x == 0 && d.knn_order != GD_KNN_SET_ORDER)
         order_waves<256>(d, d.W * (A_T / AW), reinterpret_cast<unsigned int *>(s_rows));
     const size_t agents = (size_t)d.W * A_T;
@@ -542,19 +546,53 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
     // row-major order, one piece per thread and pass; an agent's rows are 450 pieces, so the pieces of agents that must not
     // be written (padding agents, beyond the tensor) are skipped whole.  Streaming (nt) stores: the rows are written once
     // and not read again by the step, and must not push the road and agent arrays out of L2 / Infinity Cache.
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        if (act)
-            road_row(s_rows + dst[u] * 9, in[u], d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST, pose.x, pose.y, pose.z, pose.w,
-                     q0[u], q1[u]);
-    }
-    __syncthreads();
-    float *out = d.agent_map + a0 * (size_t)(K * 9);  // a0 * 7200 bytes: 16-byte aligned
     typedef float f4 __attribute__((ext_vector_type(4)));
-    constexpr int PPA = K * 9 / 4;  // pieces per agent
-    for (int q = threadIdx.x; q < RB * 9 / 4; q += 256) {
-        if (s_on[q / PPA] != 0)
-            __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + (size_t)q * 4));
+    const bool knn = d.p.roadObservationAlgorithm == GD_ROADS_K_NEAREST;
+    if (!PACK) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (act) road_row(s_rows + dst[u] * 9, in[u], knn, pose.x, pose.y, pose.z, pose.w, q0[u], q1[u]);
+        }
+        __syncthreads();
+        float *out = d.agent_map + a0 * (size_t)(K * 9);  // a0 * 7200 bytes: 16-byte aligned
+        constexpr int PPA = K * 9 / 4;  // pieces per agent
+        for (int q = threadIdx.x; q < RB * 9 / 4; q += 256) {
+            if (s_on[q / PPA] != 0)
+                __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + (size_t)q * 4));
+        }
+    } else {
+        float raw[U][9];
+#pragma unroll
+        for (int u = 0; u < U; u++) road_row(raw[u], in[u], knn, pose.x, pose.y, pose.z, pose.w, q0[u], q1[u]);
+        if (!d.pack_only) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!act) continue;
+#pragma unroll
+                for (int c = 0; c < 9; c++) s_rows[dst[u] * 9 + c] = raw[u][c];
+            }
+            __syncthreads();
+            float *out = d.agent_map + a0 * (size_t)(K * 9);
+            constexpr int PPA = K * 9 / 4;
+            for (int q = threadIdx.x; q < RB * 9 / 4; q += 256) {
+                if (s_on[q / PPA] != 0)
+                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + (size_t)q * 4));
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (act) pack_road_row(raw[u], s_rows + dst[u] * 13);
+        }
+        __syncthreads();
+        constexpr int PACK_ROAD0 = 6 + (A_T - 1) * 6, PACK_D = PACK_ROAD0 + K * 13, PPA13 = K * 13 / 4;
+        static_assert(PACK_ROAD0 % 4 == 0 && PACK_D % 4 == 0, "whole 16-byte pieces");
+        for (int q = threadIdx.x; q < RB * 13 / 4; q += 256) {
+            const int ag = q / PPA13;
+            if (s_on[ag] != 0)
+                __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4),
+                                            reinterpret_cast<f4 *>(d.pack + (a0 + ag) * (size_t)PACK_D + PACK_ROAD0 + (size_t)(q - ag * PPA13) * 4));
+        }
     }
     if (on && qf == 0) d.pose_stamp[wa] = make_uint4(__float_as_uint(pose.x), __float_as_uint(pose.y), __float_as_uint(pose.z), __float_as_uint(pose.w));
 }
@@ -1525,7 +1563,15 @@ void launch_map_obs(const DevSim &d, hipStream_t st) {
         else hipLaunchKernelGGL((k_map_obs<128>), grid, dim3(64), 0, st, d);
     }
     const size_t agents = (size_t)d.W * d.A;
-    const dim3 rgrid((unsigned int)((agents + ROWS_AB - 1) / ROWS_AB + 7) / 8 * 8);
+    if (d.pack != nullptr) {
+        constexpr int AB = RowsGeo<true>::AB;
+        const dim3 pgrid((unsigned int)((agents + AB - 1) / AB + 7) / 8 * 8);
+        if (d.A == 64) hipLaunchKernelGGL((k_map_rows<64, true>), pgrid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((k_map_rows<128, true>), pgrid, dim3(256), 0, st, d);
+        return;
+    }
+    constexpr int AB = RowsGeo<false>::AB;
+    const dim3 rgrid((unsigned int)((agents + AB - 1) / AB + 7) / 8 * 8);
     if (d.A == 64) hipLaunchKernelGGL((k_map_rows<64>), rgrid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((k_map_rows<128>), rgrid, dim3(256), 0, st, d);
 }

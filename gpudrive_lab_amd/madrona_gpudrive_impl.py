@@ -332,10 +332,10 @@ class SimManager:
         """Extension: from now on the step itself writes the packed observation (ego + partner columns by the state kernel,
         the 200 x 13 road columns by the road kernel) instead of `packed_observations()` making a second pass over the raw
         tensors; `packed_observations()` then just returns that tensor.  `only=True`: the raw partner / road rows of live
-        agents are no longer written (a learner that reads nothing else).  Returns False -- and changes nothing -- when this
-        configuration's road kernel does not store the rows itself (k-NN selection in the reference's row order): the
-        second-pass `packed_observations()` keeps working there.  GPUDRIVE_DIRECT_PACK=1 (raw rows kept) / 2 (only) at
-        construction does the same for an unchanged caller."""
+        agents are no longer written (a learner that reads nothing else).  Returns False -- and changes nothing -- where it
+        is not available (disableClassicalObs; the developer switch GPUDRIVE_LINEAR_LEGACY=1): the second-pass
+        `packed_observations()` keeps working there.  GPUDRIVE_DIRECT_PACK=1 (raw rows kept) / 2 (only) at construction does
+        the same for an unchanged caller."""
         import torch
         D = 6 + (self._A - 1) * 6 + kMaxAgentMapObservationsCount * 13
         if out is None:

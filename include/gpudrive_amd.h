@@ -161,9 +161,9 @@ int gd_pack_observations(gd_sim *sim, float *out, int64_t out_bytes);
  * until it is detached (out = NULL) or the simulator is destroyed.  only != 0: the raw partner_observations and
  * agent_roadmap rows of live agents are no longer written (for a learner that reads nothing but the packed tensor --
  * gpudrive/env/env_torch.py:756-896 is the only consumer of those rows in the reference's PPO loop); only = 0 keeps them.
- * GD_ERR_UNSUPPORTED when this configuration's road kernel does not store the rows itself (the k-NN selection in the
- * reference's row order): keep calling gd_pack_observations there.  With a buffer attached gd_pack_observations is a no-op
- * for that buffer and a device copy for any other. */
+ * Every road path writes them (the linear scan, the fused set-order kernel, k_map_rows behind the reference-order
+ * selections); GD_ERR_UNSUPPORTED only with disableClassicalObs or the developer switch GPUDRIVE_LINEAR_LEGACY=1.  With a
+ * buffer attached gd_pack_observations is a no-op for that buffer and a device copy for any other. */
 int gd_attach_packed(gd_sim *sim, float *out, int64_t out_bytes, int32_t only);
 /* Expert-action export: GPUDriveTorchEnv.get_expert_actions()
  * (gpudrive/env/env_torch.py:1445-1509 over gpudrive/datatypes/trajectory.py:24-41) in one pass over the

@@ -180,16 +180,27 @@ DIRECT_PACK = [
     ("set_order_128", [SCENE_4, SCENE_407], 128, 1, dict(WAYMO_LINEAR, roadObservationAlgorithm=0, collisionBehaviour=0)),
     ("linear_ppo_default", [TEST_JSON, SCENE_407, SCENE_4], 128, 0, PPO_DEFAULT),
     ("linear_64_set_order_flag", [SCENE_407, SCENE_4], 64, 1, WAYMO_LINEAR),
+    # k_map_rows behind the reference-order selections (rank replay forced on for these small worlds; history replay) and behind
+    # the unfused set-order selection
+    ("reference_order_rank_replay", [TEST_JSON, SCENE_407, SCENE_4], 64, 0, dict(WAYMO_LINEAR, roadObservationAlgorithm=0)),
+    ("reference_order_history_replay_128", [SCENE_4, SCENE_407], 128, 0, dict(WAYMO_LINEAR, roadObservationAlgorithm=0)),
+    ("set_order_row_kernel", [TEST_JSON, SCENE_4], 64, 1, dict(WAYMO_LINEAR, roadObservationAlgorithm=0)),
 ]
 
 
 @pytest.mark.parametrize("name,scenes,slots,knn_order,kw", DIRECT_PACK, ids=[c[0] for c in DIRECT_PACK])
-def test_packed_observation_written_by_the_step_equals_the_second_pass(name, scenes, slots, knn_order, kw):
+def test_packed_observation_written_by_the_step_equals_the_second_pass(monkeypatch, name, scenes, slots, knn_order, kw):
     """gd_attach_packed: the packed observation written where the rows are produced (k_world_step: ego + partner columns;
     the road kernel: 200 x 13 road columns) must be bit-identical to k_pack_obs's second pass over the raw tensors -- which
     tests/golden/obs_pack_golden.npz pins to the reference's own gpudrive/datatypes code -- on three simulators fed the
     same actions: raw tensors + second pass, direct with the raw rows kept, direct ONLY.  Through steps, a partial reset, a
     set_maps and a deleteAgents; padding agents' rows included."""
+    if name == "reference_order_rank_replay":
+        monkeypatch.setenv("GPUDRIVE_RANK_MIN_ROADS", "200")
+    if name == "reference_order_history_replay_128":
+        monkeypatch.setenv("GPUDRIVE_NO_RANK_REPLAY", "1")
+    if name == "set_order_row_kernel":
+        monkeypatch.setenv("GPUDRIVE_SET_FUSED_ROWS", "0")
     ref = P.make_gpu_sim(scenes, max_agents=slots, knn_order=knn_order, **kw)
     both = P.make_gpu_sim(scenes, max_agents=slots, knn_order=knn_order, **kw)
     only = P.make_gpu_sim(scenes, max_agents=slots, knn_order=knn_order, **kw)
@@ -235,11 +246,11 @@ def test_packed_observation_written_by_the_step_equals_the_second_pass(name, sce
         s.close()
 
 
-def test_direct_pack_is_refused_where_the_road_kernel_does_not_store_the_rows():
-    """Reference row order of the k-NN selection: gd_attach_packed answers GD_ERR_UNSUPPORTED, nothing changes, and the
-    second-pass packed_observations() keeps working."""
-    kw = dict(WAYMO_LINEAR, roadObservationAlgorithm=0)
-    gpu = P.make_gpu_sim([SCENE_407], max_agents=64, knn_order=0, **kw)
+def test_direct_pack_is_refused_where_it_is_not_available(monkeypatch):
+    """disableClassicalObs (no rows at all) and the developer switch GPUDRIVE_LINEAR_LEGACY=1: gd_attach_packed answers
+    GD_ERR_UNSUPPORTED, nothing changes, and the second-pass packed_observations() keeps working."""
+    monkeypatch.setenv("GPUDRIVE_LINEAR_LEGACY", "1")
+    gpu = P.make_gpu_sim([SCENE_407], max_agents=64, **WAYMO_LINEAR)
     before = _bits(gpu.packed_observations()).copy()
     assert gpu.direct_pack(only=True) is False
     assert np.array_equal(_bits(gpu.packed_observations()), before)

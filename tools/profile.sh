@@ -19,3 +19,5 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
 done
 python3 tools/profile_summarize.py $OUT
+# gpurun merges at most 64 MiB back: the raw traces and counter dumps (50-70 MB per tag) stay on the box, the summaries travel
+rm -rf $OUT/trace $OUT/pmc_[0-9]*
