@@ -156,3 +156,56 @@ def test_scene_tiling_matches_reference_dataloader_golden():
         assert sharding.scene_list_for_rank(files, case["batch"], 0) == case["indices"]
         two = sharding.scene_list_for_rank(files, case["batch"], 0) + sharding.scene_list_for_rank(files, case["batch"], 1)
         assert two == [files[i % len(files)] for i in range(2 * case["batch"])]
+
+
+_WORKER8 = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch
+    from gpudrive_lab_amd import sharding
+    rank, local_rank, world = sharding.init_process_group(backend="gloo")
+    assert world == 8
+    dev = torch.device("cpu")
+    W, A, D = 2, 64, 6 + 63 * 6 + 200 * 13
+    lo, hi = sharding.shard_range(8 * W, rank, world)
+    assert (lo, hi) == (rank * W, rank * W + W)
+    obs = torch.full((W, A, D), float(rank)) + torch.arange(W * A, dtype=torch.float32).view(W, A, 1) / 1024.0
+    g = torch.Generator().manual_seed(40 + rank)
+    ctrl = torch.rand(W, A, generator=g) < 0.1 + 0.1 * rank          # 10 to 80 percent controlled: very unequal blocks
+    for mode in ("raw", "compact"):
+        og = sharding.ObservationGather(mode, W * A, D, dev)
+        og.set_mask(ctrl)
+        for step in range(3):
+            og.start(obs + step)
+            full, counts = og.wait()
+        assert full.shape == (8 * og.cap, D) and len(counts) == 8
+        for r in range(8):
+            gr = torch.Generator().manual_seed(40 + r)
+            cr = torch.rand(W, A, generator=gr) < 0.1 + 0.1 * r
+            exp = (torch.full((W, A, D), float(r)) + torch.arange(W * A, dtype=torch.float32).view(W, A, 1) / 1024.0 + 2).reshape(-1, D)
+            if mode == "compact":
+                exp = exp[cr.reshape(-1)]
+                assert int(counts[r]) == int(cr.sum())
+            assert torch.equal(full[r * og.cap:r * og.cap + exp.shape[0]], exp), (mode, r)
+    assert sharding.reduce_sum(1, dev) == 8.0 and sharding.reduce_max(rank, dev) == 7.0
+    torch.distributed.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_eight_rank_gloo_gather(tmp_path):
+    """Config 4's shape of job -- 8 ranks, contiguous world blocks, the observation gathered in both modes with controlled
+    shares from 10 % to 80 % -- on gloo, so that the first RCCL run of ObservationGather is not also its first 8-rank run."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8 % ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and "ok" in out, out
