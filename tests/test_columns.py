@@ -137,6 +137,55 @@ def check_road_selection_by_brute_force(sim, radius, as_numpy=np.array, K=200, m
     return checked
 
 
+def check_linear_selection_by_brute_force(sim, radius, as_numpy=np.array, K=200, margin=1e-3):
+    """Linear mode (AllEntitiesWithRadiusFiltering, reference src/sim.cpp:258-279), independent of the oracle: an agent's
+    non-padding rows are, IN THIS ORDER, the first K global roads in index order that lie within the radius -- computed here in
+    float64 from the absolute poses and the global road rows (roads within `margin` of the radius may go either way, so the
+    expected sequence is built from the roads the kernel chose among those); every row must be that road's ego-frame image;
+    the rows behind them are MapObservation::zero() (id -1, mapType -1)."""
+    ab = as_numpy(sim.absolute_self_observation_tensor()).astype(np.float64)
+    rm = as_numpy(sim.agent_roadmap_tensor()).astype(np.float64)
+    mo = as_numpy(sim.map_observation_tensor()).astype(np.float64)
+    shape = as_numpy(sim.shape_tensor())
+    A, R = COL.ABS_OBS, COL.ROAD_ROW
+    checked = full = 0
+    for w in range(ab.shape[0]):
+        n, nr = int(shape[w, 0]), int(shape[w, 1])
+        gl = mo[w, :nr]
+        for i in range(n):
+            pos = ab[w, i, [A["pos_x"], A["pos_y"]]]
+            yaw = ab[w, i, A["rotation_angle"]]
+            d = np.hypot(gl[:, R["x"]] - pos[0], gl[:, R["y"]] - pos[1])
+            sure, maybe = d < radius - margin, d <= radius + margin
+            rows = rm[w, i]
+            live = ~((rows[:, R["type"]] == 0) & (rows[:, R["id"]] == -1))
+            k = int(live.sum())
+            assert live[:k].all() and not live[k:].any(), (w, i, "padding rows must follow the road rows")
+            assert (rows[k:, :6] == 0).all() and (rows[k:, R["id"]] == -1).all() and (rows[k:, R["vbd_type"]] == -1).all(), (w, i)
+            # the kernel's rows -> global road indices, through the ego-frame position and the type, in ascending order
+            c, s_ = np.cos(yaw), np.sin(yaw)
+            gx = pos[0] + c * rows[:k, R["x"]] - s_ * rows[:k, R["y"]]
+            gy = pos[1] + s_ * rows[:k, R["x"]] + c * rows[:k, R["y"]]
+            chosen, last = [], -1
+            for x, y, t in zip(gx, gy, rows[:k, R["type"]]):
+                cand = np.where((np.hypot(gl[:, R["x"]] - x, gl[:, R["y"]] - y) < 1e-3) & (gl[:, R["type"]] == t))[0]
+                cand = cand[cand > last]   # (duplicated points: the next one in index order)
+                assert len(cand), (w, i, "a row is no road of this world, or the rows are not in index order")
+                last = int(cand[0])
+                chosen.append(last)
+            chosen = np.array(chosen, int)
+            assert maybe[chosen].all(), (w, i, "a road beyond the radius was selected")
+            # every road that is certainly in reach and comes before the last selected one (or anywhere, if fewer than K were
+            # selected) must be among the selected
+            limit = chosen[-1] if k == K else nr
+            missing = [r for r in np.where(sure)[0] if r <= limit and r not in set(chosen.tolist())]
+            assert not missing, (w, i, "roads in reach were skipped", missing[:5])
+            assert k <= K
+            checked += 1
+            full += k == K
+    return checked, full
+
+
 def check_partner_rows_by_brute_force(sim, radius, as_numpy=np.array, margin=1e-3, atol=2e-4):
     """collectPartnerObsSystem (reference src/sim.cpp:188-240) recomputed in float64 numpy from the ABSOLUTE rows,
     independently of the oracle: slot k of ego i is agent j = k-th other agent in index order; within the radius
@@ -213,3 +262,19 @@ def test_road_selection_by_brute_force_when_K_binds(oracle_mod):
     sim = O.OracleSim([TEST_JSON], p, max_agents=64)
     assert int(sim.shape_tensor()[0, 1]) == 9899
     assert check_road_selection_by_brute_force(sim, 100.0) == 25
+
+
+def test_linear_selection_by_brute_force_on_the_oracle(oracle_mod):
+    """Linear mode pinned without the oracle's own loop: float64 brute force over the global rows (and the same on the HIP
+    path, tests/test_gpu_round5.py).  Unreduced polylines and a 60 m radius: K binds for many agents (the early exit)."""
+    O = oracle_mod
+    p = O.default_params(polylineReductionThreshold=0.0, observationRadius=60.0, collisionBehaviour=2, roadObservationAlgorithm=1,
+                         isStaticAgentControlled=1, initOnlyValidAgentsAtFirstStep=0)
+    sim = O.OracleSim([TEST_JSON, SCENE_4], p, max_agents=64)
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        act = sim.action_tensor()
+        act[..., 0] = rng.uniform(-1, 2, act.shape[:2]); act[..., 1] = rng.uniform(-0.5, 0.5, act.shape[:2])
+        sim.step()
+    checked, full = check_linear_selection_by_brute_force(sim, 60.0)
+    assert checked == 25 + 64 and full > 10

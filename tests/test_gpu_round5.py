@@ -346,3 +346,20 @@ def test_rank_buffers_that_cannot_be_allocated_leave_the_batch_on_the_history_re
     assert gpu.stat(7) == 0 and gpu.stat(21) == 0
     P.compare_fresh(gpu, orc)
     gpu.close()
+
+
+def test_linear_selection_by_brute_force_on_the_hip_path():
+    """The oracle-independent pin of linear mode (tests/test_columns.py): float64 brute force over the global road rows -- the
+    first K roads in index order within the radius, in that order, each row the road's ego-frame image -- on the HIP path,
+    unreduced polylines (K binds: the scan's early exit) and the reduced scenes."""
+    from tests.test_columns import check_linear_selection_by_brute_force
+    for thr, radius in ((0.0, 60.0), (0.1, 50.0)):
+        kw = dict(BENCH_LINEAR, polylineReductionThreshold=thr, observationRadius=radius)
+        gpu = P.make_gpu_sim([TEST_JSON, SCENE_4], max_agents=64, **kw)
+        rng = np.random.default_rng(4)
+        for _ in range(3):
+            RC.write_actions(gpu, P.random_actions(rng, 2, 64, 0))
+            gpu.step()
+        checked, full = check_linear_selection_by_brute_force(gpu, radius, as_numpy=RC.as_np)
+        assert checked == 25 + 64 and (full > 10 or thr > 0)
+        gpu.close()
