@@ -366,7 +366,7 @@ def _bench_workload(name, args, rank, local_rank, world, device):
             tkey = ("set_" if knn_order == 1 else "exact_") + workload
         else:  # lidar, bev, rl_loop: collected in the default (reference) row order only
             tkey = workload if knn_order == 0 else ({"cfg3": "set_cfg3", "rl_loop": "rl_loop_set"}.get(workload))
-        if agents_override:
+        if agents_override and workload != "ppo_default":
             tkey = (tkey or "") + "_128"
         stamp = source_stamp()
         for tname in sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_traffic.json") and n[:1] == "r"),

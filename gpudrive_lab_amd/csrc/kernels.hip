@@ -200,61 +200,93 @@ __device__ unsigned long long g_step_cnt[4];  // road-box items, items that pass
 // of STEP_THREADS consecutive 36-byte rows is assembled in LDS (row stride 9 floats: conflict-free) and leaves as whole
 // 16-byte pieces with streaming stores (a world's block starts at a multiple of 16 bytes and so does every chunk; only the
 // piece that straddles the end of the live egos' rows goes element by element).
+// One partner row into o[0..9): ego's view of the partner in slot k (OtherAgents order, src/level_gen.cpp:450-464), k < n - 1.
+// Every rotation is a yaw rotation: rotateVec and the Hamilton product with the terms that multiply the zero x / y components
+// dropped (gd_math.hpp rotate_yaw; map_rows.hpp road_row has the argument: every non-zero result is the same float, a zero may
+// change its sign, which only the heading of an exactly opposite partner can see -- that case keeps the full product).
+// `length() > radius` on the squared length (engine.cpp radius_key_max).
+__device__ __forceinline__ void partner_row(float *o, const DevSim &d, int ego, int k, const float *s_px, const float *s_py, const float *s_qw,
+                                            const float *s_qz, const float *s_speed, const float *s_len, const float *s_wid,
+                                            const float *s_hgt, const int *s_etype, const int *s_id) {
+    const int j = k < ego ? k : k + 1;
+    const float ew = s_qw[ego], ez = s_qz[ego];
+    const V2 r = rotate_yaw(ew, -ez, s_px[j] - s_px[ego], s_py[j] - s_py[ego]);
+    if (r.x * r.x + r.y * r.y > d.radius_key_max) {  // zero(): id -1
+        o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -1.f;
+        return;
+    }
+    const float rw = s_qw[j], rz = s_qz[j], iz = -ez;
+    const float pw = ew * rw - iz * rz, pz = ew * rz + iz * rw;  // (w, z) of inverse(ego) * other
+    const float wz = pw * pz;
+    float heading;
+    if (wz != 0.f) heading = atan2f(2.0f * wz, 1.0f - 2.0f * (pz * pz));
+    else heading = quat_to_yaw_row(quat_mul(quat_inv(quat_from_wz(ew, ez)), quat_from_wz(rw, rz)));
+    o[0] = s_speed[j];
+    o[1] = r.x; o[2] = r.y;
+    o[3] = heading;
+    o[4] = s_len[j]; o[5] = s_wid[j]; o[6] = s_hgt[j];
+    o[7] = (float)s_etype[j];
+    o[8] = (float)s_id[j];
+}
+
+// `write_const` = false (step passes) leaves out what cannot have changed since the last pass that wrote everything: the rows of
+// partner slots beyond the world's agents (zero_nonexist(), id -2: a function of the world's agent count alone -- 104 of an
+// agent's 127 rows in a Waymo scene of 24 vehicles under this fork's 128 slots).  Reset passes follow every rebuild of the worlds
+// (gd_create, set_maps, deleteAgents) and write everything.  In a ragged world a step pass therefore computes and stores n (n - 1)
+// rows instead of n (A - 1): an ego's real rows are one contiguous piece of its block (not 16-byte aligned: they leave float by
+// float, consecutive threads to consecutive addresses); a full world (n == A) has no such rows and takes the aligned path.
 template <int A_T>
 __device__ __forceinline__ void partner_rows(const DevSim &d, int w, int n, int a, const float *s_px, const float *s_py,
                                              const float *s_qw, const float *s_qz, const float *s_speed, const float *s_len,
-                                             const float *s_wid, const float *s_hgt, const int *s_etype, const int *s_id) {
-    {
-        __shared__ __attribute__((aligned(16))) float s_rows[STEP_THREADS * 9];
-        const int rows = n * (A_T - 1);
-        float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
-        typedef float f4 __attribute__((ext_vector_type(4)));
+                                             const float *s_wid, const float *s_hgt, const int *s_etype, const int *s_id,
+                                             bool write_const) {
+    __shared__ __attribute__((aligned(16))) float s_rows[STEP_THREADS * 9];
+    float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (!write_const && n < A_T) {
+        const int m = n - 1;  // real partners per ego
+        const int rows = n * m;
         for (int p0 = 0; p0 < rows; p0 += STEP_THREADS) {
             if (GD_DIAG_IS(d.step_dbg, 3)) break;
             const int p = p0 + a;
             if (p < rows) {
-                const int ego = p / (A_T - 1), k = p - ego * (A_T - 1);
-                float *o = s_rows + a * 9;
-                if (k >= n - 1) {  // zero_nonexist(): id -2
-                    o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -2.f;
-                } else {
-                    const int j = k < ego ? k : k + 1;  // OtherAgents order, src/level_gen.cpp:450-464
-                    // Every rotation is a yaw rotation: rotateVec and the Hamilton product with the terms that multiply the zero x / y
-                    // components dropped (gd_math.hpp rotate_yaw; map_rows.hpp road_row has the argument: every non-zero result is the
-                    // same float, a zero may change its sign, which only the heading of an exactly opposite partner can see -- that
-                    // case keeps the full product).  `length() > radius` on the squared length (engine.cpp radius_key_max).
-                    const float ew = s_qw[ego], ez = s_qz[ego];
-                    const V2 r = rotate_yaw(ew, -ez, s_px[j] - s_px[ego], s_py[j] - s_py[ego]);
-                    if (r.x * r.x + r.y * r.y > d.radius_key_max) {  // zero(): id -1
-                        o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -1.f;
-                    } else {
-                        const float rw = s_qw[j], rz = s_qz[j], iz = -ez;
-                        const float pw = ew * rw - iz * rz, pz = ew * rz + iz * rw;  // (w, z) of inverse(ego) * other
-                        const float wz = pw * pz;
-                        float heading;
-                        if (wz != 0.f) heading = atan2f(2.0f * wz, 1.0f - 2.0f * (pz * pz));
-                        else heading = quat_to_yaw_row(quat_mul(quat_inv(quat_from_wz(ew, ez)), quat_from_wz(rw, rz)));
-                        o[0] = s_speed[j];
-                        o[1] = r.x; o[2] = r.y;
-                        o[3] = heading;
-                        o[4] = s_len[j]; o[5] = s_wid[j]; o[6] = s_hgt[j];
-                        o[7] = (float)s_etype[j];
-                        o[8] = (float)s_id[j];
-                    }
-                }
+                const int ego = p / m;
+                partner_row(s_rows + a * 9, d, ego, p - ego * m, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id);
             }
             __syncthreads();
-            const int nf = min(STEP_THREADS, rows - p0) * 9;  // floats of this chunk
-            float *out = base + (size_t)p0 * 9;
-            for (int q = a; q * 4 < nf; q += STEP_THREADS) {
-                if (q * 4 + 4 <= nf) {
-                    __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + q * 4));
-                } else {
-                    for (int e = q * 4; e < nf; e++) out[e] = s_rows[e];
-                }
+            const int nf = min(STEP_THREADS, rows - p0) * 9;  // floats of this chunk: float f of it is float p0 * 9 + f of the real rows
+            for (int f = a; f < nf; f += STEP_THREADS) {
+                const int gf = p0 * 9 + f, ego = gf / (m * 9);
+                __builtin_nontemporal_store(s_rows[f], base + (size_t)ego * (A_T - 1) * 9 + (gf - ego * m * 9));
             }
             __syncthreads();
         }
+        return;
+    }
+    const int rows = n * (A_T - 1);
+    for (int p0 = 0; p0 < rows; p0 += STEP_THREADS) {
+        if (GD_DIAG_IS(d.step_dbg, 3)) break;
+        const int p = p0 + a;
+        if (p < rows) {
+            const int ego = p / (A_T - 1), k = p - ego * (A_T - 1);
+            float *o = s_rows + a * 9;
+            if (k >= n - 1) {  // zero_nonexist(): id -2
+                o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = (float)ET_None; o[8] = -2.f;
+            } else {
+                partner_row(o, d, ego, k, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id);
+            }
+        }
+        __syncthreads();
+        const int nf = min(STEP_THREADS, rows - p0) * 9;  // floats of this chunk
+        float *out = base + (size_t)p0 * 9;
+        for (int q = a; q * 4 < nf; q += STEP_THREADS) {
+            if (q * 4 + 4 <= nf) {
+                __builtin_nontemporal_store(*reinterpret_cast<const f4 *>(s_rows + q * 4), reinterpret_cast<f4 *>(out + q * 4));
+            } else {
+                for (int e = q * 4; e < nf; e++) out[e] = s_rows[e];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -649,7 +681,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     STEP_PHASE(5);
     // ---- collectPartnerObsSystem, :188-240: here, or in k_partner_rows on a stream of its own beside the road kernels ----
     if (!d.p.disableClassicalObs && !d.split_partner && !d.pack_only)
-        partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id);
+        partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id, !MOVE || d.pose_skip == 0);
     if (d.pack != nullptr && !d.p.disableClassicalObs) {
         __syncthreads();  // the agent threads' self columns
         packed_head<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_self);
@@ -678,7 +710,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_partner_rows(DevSim d) {
         s_id[a] = d.agent_id[i];
     }
     __syncthreads();
-    partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id);
+    partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id, true);
 }
 
 }  // namespace

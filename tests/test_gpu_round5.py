@@ -363,3 +363,45 @@ def test_linear_selection_by_brute_force_on_the_hip_path():
         checked, full = check_linear_selection_by_brute_force(gpu, radius, as_numpy=RC.as_np)
         assert checked == 25 + 64 and (full > 10 or thr > 0)
         gpu.close()
+
+
+def test_partner_rows_beyond_the_worlds_agents_are_written_by_reset_passes_only(oracle_mod):
+    """A step pass leaves the rows of partner slots beyond the world's agents (zero_nonexist(), id -2: a function of the agent
+    count alone) where the last reset pass put them and writes only the n (n - 1) real rows of a ragged world; a reset pass
+    writes every row.  Free-running steps (no teacher forcing in between, which would be a reset pass) must still show the
+    oracle's partner tensor; garbage written from outside survives a step exactly in those rows and nowhere else, and is
+    gone after any reset pass."""
+    import torch
+    scenes = [TEST_JSON, SCENE_407, SCENE_4]
+    gpu = P.make_gpu_sim(scenes, max_agents=128, **PPO_DEFAULT)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=128, **PPO_DEFAULT)
+    rng = np.random.default_rng(12)
+    for _ in range(6):
+        act = P.random_actions(rng, 3, 128, 0)
+        RC.write_actions(gpu, act)
+        np.copyto(orc.action_tensor(), act)
+        gpu.step()
+        orc.step()
+    P.compare_obs(gpu, orc, atol=P.FREE_OBS_ATOL, names=["partner_observations_tensor"])
+    part = gpu.partner_observations_tensor().to_torch()
+    n = gpu.shape_tensor().to_torch()[:, 0]
+    live = torch.arange(part.shape[1], device=part.device)[None, :] < n[:, None]
+    part[live] = 55.0
+    act = P.random_actions(rng, 3, 128, 0)
+    RC.write_actions(gpu, act)
+    np.copyto(orc.action_tensor(), act)
+    gpu.step()
+    orc.step()
+    g = RC.as_np(gpu.partner_observations_tensor())
+    o = np.asarray(orc.partner_observations_tensor())
+    lv = RC.as_np(live)
+    survived = (g == 55.0).all(-1) & lv[:, :, None]
+    assert survived.any(), "a step pass should have left the constant rows alone"
+    assert (o[survived][:, 8] == -2.0).all(), "only rows of partner slots beyond the world's agents may be left in place"
+    real = lv[:, :, None] & ~survived
+    assert np.allclose(g[real], o[real], atol=P.FREE_OBS_ATOL)
+    assert (o[real][:, 8] != -2.0).all(), "every real partner row must have been written"
+    gpu.reset([])
+    orc.reset([])
+    P.compare_obs(gpu, orc, atol=P.FREE_OBS_ATOL, names=["partner_observations_tensor"])
+    gpu.close()
