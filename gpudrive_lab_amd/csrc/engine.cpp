@@ -133,7 +133,12 @@ struct gd_sim {
     // inside the captured step graph
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    size_t lin_cap = 0;        // entries of d.lin_groups
+    size_t lin_cap = 0;        // entries of d.lin_list / d.lin_list_dyn
+    int32_t *d_lin_list = nullptr, *d_lin_list_dyn = nullptr;
+    std::vector<std::vector<int32_t>> w_resp;  // response type of every agent slot (who can move at all)
+    bool full_pass_next = false;  // the next step's road pass takes every live agent (state was written from outside)
+    int64_t lin_static_agents = 0;   // live agents that are not on the step passes' list (response type Static)
+    int64_t host_skipped = 0;        // ... counted as left in place once per step pass (gd_stat 30 adds the device's counters)
     bool rk_possible = false;  // reference order, k-NN, not switched off: a batch may take the rank replay
     bool rk_alloc = false;     // its buffers exist
 
@@ -301,6 +306,22 @@ struct gd_sim {
     }
 
     void step() {
+        if (full_pass_next) {  // (gd_debug_set_state moved agents behind the engine's back: nobody is left out of this step's road pass)
+            full_pass_next = false;
+            d.lin_dyn_off = 1;
+            try {
+                run_rest(true);
+            } catch (...) {
+                d.lin_dyn_off = 0;
+                throw;
+            }
+            d.lin_dyn_off = 0;
+            stat_plain_steps++;
+            return;
+        }
+        // (the agents a linear step pass does not even visit are agents whose rows are left in place)
+        if (params.roadObservationAlgorithm != GD_ROADS_K_NEAREST && d.lin_on && d.pose_skip && !params.disableClassicalObs)
+            host_skipped += lin_static_agents;
         if (!graph_ok || timing || stream == nullptr) {  // the legacy null stream cannot be captured
             run_rest(true);
             stat_plain_steps++;
@@ -502,6 +523,7 @@ struct gd_sim {
             st.shape.push_back(hw->num_roads);
             w_xy[w] = hw->road_xy;
             w_agents[w] = hw->num_agents;
+            w_resp[w] = hw->resp;
             w_aux[w] = hw->road_aux;
             w_boxes[w] = hw->boxes;
             w_grid[w] = gd::GridHdr{hw->grid_ox, hw->grid_oy, 1.f / hw->grid_cell, hw->grid_nx, hw->grid_ny, 0, 0, 0};
@@ -727,28 +749,43 @@ struct gd_sim {
             if (!groups.empty()) HIP_CHECK(hipMemcpy(d.set_groups, groups.data(), sizeof(int32_t) * groups.size(), hipMemcpyHostToDevice));
         }
         {
-            // the linear scan's workgroups (4 waves x lin_apw agents each), world-major inside eight classes that are interleaved
-            // entry by entry: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, dispatch), so every workgroup of a world -- and the
-            // world's road arrays -- stays on one XCD's L2.  Classes are filled greedily (fewest workgroups so far) so that ragged
-            // batches leave few filler entries.
+            // The linear scan's work lists: the live agents as (world << 8 | agent), world-major inside eight classes, the classes
+            // interleaved workgroup by workgroup (4 * lin_apw entries each): workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md,
+            // dispatch), so every workgroup that holds agents of a world -- and the world's road arrays -- stays on one XCD's L2.
+            // Classes are filled greedily (fewest entries so far) so that ragged batches leave few filler entries.  Two lists:
+            // every live agent (reset passes), and the agents that can move (step passes: a `Static` agent's rows were written
+            // by the reset pass that follows every rebuild, and nothing moves it afterwards).
             const int per = 4 * d.lin_apw;
-            std::vector<int32_t> seq[8];
-            for (int w = 0; w < W; w++) {
-                const int ng = (w_agents[w] + per - 1) / per;
-                if (ng == 0) continue;
-                int c = w % 8;
-                for (int k = 0; k < 8; k++)
-                    if (seq[k].size() + 4 * static_cast<size_t>(A / per) < seq[c].size()) c = k;  // only when a class runs far ahead
-                for (int g = 0; g < ng; g++) seq[c].push_back(w << 8 | g);
-            }
-            size_t len = 0;
-            for (auto &q : seq) len = std::max(len, q.size());
-            std::vector<int32_t> list(len * 8, -1);
-            for (int c = 0; c < 8; c++)
-                for (size_t j = 0; j < seq[c].size(); j++) list[j * 8 + c] = seq[c][j];
-            if (list.size() > lin_cap) throw std::runtime_error("linear-scan work list: more workgroups than the list holds");
-            d.lin_group_count = static_cast<int>(list.size());
-            if (!list.empty()) HIP_CHECK(hipMemcpy(d.lin_groups, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice));
+            auto build = [&](bool dyn_only, std::vector<int32_t> &list) -> int {
+                std::vector<int32_t> seq[8];
+                for (int w = 0; w < W; w++) {
+                    std::vector<int32_t> mine;
+                    for (int a = 0; a < w_agents[w]; a++)
+                        if (!dyn_only || w_resp[w][a] != gd::RESP_Static) mine.push_back(w << 8 | a);
+                    if (mine.empty()) continue;
+                    int c = w % 8;
+                    for (int k = 0; k < 8; k++)
+                        if (seq[k].size() + 4 * static_cast<size_t>(A) < seq[c].size()) c = k;  // only when a class runs far ahead
+                    seq[c].insert(seq[c].end(), mine.begin(), mine.end());
+                }
+                size_t blocks = 0;
+                for (auto &q : seq) blocks = std::max(blocks, (q.size() + per - 1) / per);
+                list.assign(blocks * 8 * per, -1);
+                for (int c = 0; c < 8; c++)
+                    for (size_t j = 0; j < seq[c].size(); j++) list[((j / per) * 8 + c) * per + j % per] = seq[c][j];
+                return static_cast<int>(blocks * 8);
+            };
+            std::vector<int32_t> full, dyn;
+            d.lin_blocks = build(false, full);
+            d.lin_blocks_dyn = build(true, dyn);
+            lin_static_agents = 0;
+            for (int32_t e : full) lin_static_agents += e >= 0;
+            for (int32_t e : dyn) lin_static_agents -= e >= 0;
+            if (full.size() > lin_cap || dyn.size() > lin_cap) throw std::runtime_error("linear-scan work list: more entries than the list holds");
+            if (!full.empty()) HIP_CHECK(hipMemcpy(d_lin_list, full.data(), sizeof(int32_t) * full.size(), hipMemcpyHostToDevice));
+            if (!dyn.empty()) HIP_CHECK(hipMemcpy(d_lin_list_dyn, dyn.data(), sizeof(int32_t) * dyn.size(), hipMemcpyHostToDevice));
+            d.lin_list = d_lin_list;
+            d.lin_list_dyn = d_lin_list_dyn;
         }
         launch(gd::KERNEL_PADDING, false);
         // the packed observation's rows of padding agents come from the raw padding rows just written (the live agents' rows are
@@ -1058,10 +1095,13 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.road_bbox = s->alloc_internal<float4>(W);
         d.lin_apw = 2;
         if (const char *e = std::getenv("GPUDRIVE_LIN_AGENTS_PER_WAVE")) d.lin_apw = std::min(A / 4, std::max(1, std::atoi(e)));
-        // worst case: every class as long as the longest one, which holds at most ceil(W / 8) + a few worlds' workgroups
-        s->lin_cap = (static_cast<size_t>(W) + 64) * static_cast<size_t>((A + 4 * d.lin_apw - 1) / (4 * d.lin_apw)) + 64;
-        d.lin_groups = s->alloc_internal<int32_t>(s->lin_cap);
-        d.lin_group_count = 0;
+        // worst case: every class as long as the longest one, which holds at most W / 8 + a few worlds' agents
+        s->lin_cap = (static_cast<size_t>(W) + 64) * static_cast<size_t>(A) + 8 * 4 * static_cast<size_t>(d.lin_apw) + 64;
+        s->d_lin_list = s->alloc_internal<int32_t>(s->lin_cap);
+        s->d_lin_list_dyn = s->alloc_internal<int32_t>(s->lin_cap);
+        d.lin_list = s->d_lin_list; d.lin_list_dyn = s->d_lin_list_dyn;
+        d.lin_blocks = 0; d.lin_blocks_dyn = 0; d.lin_dyn_off = 0;
+        s->w_resp.resize(W);
         d.lin_on = std::getenv("GPUDRIVE_LINEAR_LEGACY") == nullptr ? 1 : 0;
         d.pose_stamp = s->alloc_internal<uint4>(WA);
         d.pose_skip = std::getenv("GPUDRIVE_NO_POSE_SKIP") == nullptr ? 1 : 0;
@@ -1305,7 +1345,8 @@ int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
             return fail(GD_ERR_DEVICE, "gd_stat: reading the skip counters failed");
         unsigned long long sum = 0;
         for (unsigned long long x : v) sum += x;
-        *out = static_cast<int64_t>(sum);
+        *out = static_cast<int64_t>(sum) + s->host_skipped;
+        s->host_skipped = 0;
         return GD_OK;
     }
     if (s && out && which == 21) {  // bounds audit of the rank path (engine.hpp GD_RANK_AUDIT): violations since the buffers exist
@@ -1431,6 +1472,7 @@ int gd_debug_set_state(gd_sim *s, const float *in) {
         }
         for (size_t i = 0; i < WA; i++) iplane[i] = in[i * 11 + 10] != 0.f;
         HIP_CHECK(hipMemcpy(s->d.collided, iplane.data(), WA * 4, hipMemcpyHostToDevice));
+        s->full_pass_next = true;
     });
 }
 

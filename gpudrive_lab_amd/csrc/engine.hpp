@@ -113,10 +113,13 @@ struct DevSim {
     const float2 *rcell_xy;        // the (x, y) of those roads, in the same (cell-sorted) order: one coalesced stream per grid row
     const uint16_t *rcell_pos;     // [roads] the inverse: where road r of its world sits in the world's cell-sorted order (set order IS that order)
     float4 *knn_prev;              // [W][A] {x, y, K-th key of the previous selection or +inf, 0}
-    // linear road selection (map_obs_linear.hip): workgroups of 4 waves x lin_apw agent slots, (world << 8 | group) or -1 (filler),
-    // ordered so that every workgroup of a world has the same index modulo 8 (= runs on the same XCD)
-    int32_t *lin_groups;
-    int lin_group_count;
+    // linear road selection (map_obs_linear.hip): the live agents as (world << 8 | agent) or -1 (filler), 4 * lin_apw entries per
+    // workgroup, ordered so that every workgroup that holds agents of a world has the same index modulo 8 (= runs on the same
+    // XCD); lin_list_dyn: the same without the agents whose response type is Static (they never move: reference
+    // src/sim.cpp:327-331), what a step pass takes; lin_dyn_off: this pass takes the full list all the same
+    const int32_t *lin_list, *lin_list_dyn;
+    int lin_blocks, lin_blocks_dyn;
+    int lin_dyn_off;
     // ... and skip whole blocks of GD_LIN_BLK consecutive roads that cannot hold a road in reach: per block the circle around its
     // roads' points, (cx, cy, radius, 0); the blocks of world w start at blk_off[w] (roads follow their polylines in index order,
     // so a block is a short piece of one polyline as a rule)
@@ -175,9 +178,9 @@ struct DevSim {
 };
 
 void launch_kernel(const DevSim &d, hipStream_t st, int which, bool move);
-void launch_map_obs(const DevSim &d, hipStream_t st);  // map_obs.hip
+void launch_map_obs(const DevSim &d, hipStream_t st, bool move);  // map_obs.hip
 void launch_map_obs_rank(const DevSim &d, hipStream_t st);  // map_obs_rank.hip
-void launch_map_obs_linear(const DevSim &d, hipStream_t st);  // map_obs_linear.hip
+void launch_map_obs_linear(const DevSim &d, hipStream_t st, bool move);  // map_obs_linear.hip
 void launch_bev(const DevSim &d, hipStream_t st);      // bev_lidar.hip
 void launch_lidar(const DevSim &d, hipStream_t st);    // bev_lidar.hip
 void launch_pack_obs(const DevSim &d, hipStream_t st, float *out);  // pack_obs.hip

@@ -739,7 +739,7 @@ static void launch_all(const DevSim &d, hipStream_t st, int which, bool move) {
         if (move) hipLaunchKernelGGL((k_world_step<A_T, true>), grid, dim3(STEP_THREADS), 0, st, d);
         else hipLaunchKernelGGL((k_world_step<A_T, false>), grid, dim3(STEP_THREADS), 0, st, d);
         break;
-    case KERNEL_MAP_OBS: launch_map_obs(d, st); break;
+    case KERNEL_MAP_OBS: launch_map_obs(d, st, move); break;
     case KERNEL_PARTNER: hipLaunchKernelGGL(k_partner_rows<A_T>, grid, dim3(STEP_THREADS), 0, st, d); break;
     }
 }

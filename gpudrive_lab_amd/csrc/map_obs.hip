@@ -1535,10 +1535,10 @@ void set_clocks_read(unsigned long long *out) {  // and zero them
 }
 #endif
 
-void launch_map_obs(const DevSim &d, hipStream_t st) {
+void launch_map_obs(const DevSim &d, hipStream_t st, bool move) {
     // AllEntitiesWithRadiusFiltering: rows in road-index order whatever knn_order says -- a kernel of its own (map_obs_linear.hip)
     if (d.p.roadObservationAlgorithm != GD_ROADS_K_NEAREST && d.lin_on) {
-        launch_map_obs_linear(d, st);
+        launch_map_obs_linear(d, st, move);
         return;
     }
     if (d.knn_order == GD_KNN_SET_ORDER) {

@@ -25,8 +25,9 @@
 //     the rows are a function of (pose, the world's roads, the radius), and the stamp dies with the world's roads
 //     (rebuild_worlds).  Parked cars (`Static` under the reference's default isStaticAgentControlled = false, reference
 //     src/level_gen.cpp:102-113, src/sim.cpp:327-331) and finished agents are most of a Waymo scene.
-//   * workgroups are dealt to the XCDs by world (engine.cpp lin_groups: workgroup b runs on XCD b % 8, and the list puts
-//     every workgroup of a world at the same b % 8), so that a world's road arrays are fetched into one L2, not eight.
+//   * agents are dealt to the XCDs by world (engine.cpp lin_list: workgroup b runs on XCD b % 8, and the list puts every agent
+//     of a world at the same b % 8, in consecutive workgroups), so that a world's road arrays are fetched into one L2, not
+//     eight.  Step passes take a second list that leaves out the agents that never move (`Static`).
 //
 // With DevSim::pack set (gd_attach_packed) the wave also -- or only: pack_only -- writes the agent's 200 x 13 normalised road
 // columns of the packed observation (pack_cols.hpp), so that a learner that reads packed_observations() pays no second pass.
@@ -68,43 +69,46 @@ static_assert(64 % GD_LIN_BLK == 0, "whole blocks per pass");
 template <int A_T, bool PACK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GD_LIN_WPE))) void k_map_obs_linear(DevSim d) {
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
-    const int wg = d.lin_groups[blockIdx.x];
-    if (wg < 0) return;  // filler entry (the XCD classes hold different numbers of workgroups)
-    const int w = wg >> 8, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int n = d.shape[w * 2 + 0];
-    const int r0 = d.road_off[w];
-    const int R = d.road_off[w + 1] - r0;
     const int per = 4 * d.lin_apw;
-    const int a_first = (wg & 255) * per, a_end = min(n, a_first + per);
+    const int32_t *entries = d.lin_list + (size_t)blockIdx.x * per;  // (world << 8 | agent) or -1: engine.cpp lin_list
     const float kmax = d.radius_key_max;
-    const float2 *rxy = d.road_xy + r0;
 
     __shared__ unsigned short s_sel[4][K + 56];                          // the selected road indices of the wave's agent, index order
     __shared__ unsigned short s_lst[4][LST];                             // the blocks of the world's roads that may hold a road in reach
     __shared__ __attribute__((aligned(16))) float s_stage[4][64 * 13];   // 64 rows on their way out (9 raw or 13 packed columns)
     unsigned short *sel = s_sel[wave];
     unsigned short *lst = s_lst[wave];
-    const int NB = (R + GD_LIN_BLK - 1) / GD_LIN_BLK;
-    const float4 *blk = d.road_blk + d.blk_off[w];
     float *stage = s_stage[wave];
-
-    // out of reach of every road: farther than the radius (plus rounding) from the box around the world's roads
-    const float4 bb = d.road_bbox[w];
     const float reach = d.p.observationRadius * 1.001f + 0.01f;
 
-    struct Pose { float ex, ey, qw, qz; uint4 st; };
-    auto load_pose = [&](int a) -> Pose {
-        const size_t i = (size_t)w * A_T + a;
-        return Pose{d.px[i], d.py[i], d.qw[i], d.qz[i], d.pose_stamp[i]};
+    // what an agent's turn needs, requested one agent ahead: its pose and stamp, and its world's road ranges and road box
+    struct Work { int e, r0, r1, b0; float4 bb; float ex, ey, qw, qz; uint4 st; };
+    auto load_work = [&](int k) -> Work {
+        Work wk{-1, 0, 0, 0, make_float4(0.f, 0.f, 0.f, 0.f), 0.f, 0.f, 1.f, 0.f, make_uint4(0u, 0u, 0u, 0u)};
+        if (k < per) wk.e = entries[k];
+        if (wk.e >= 0) {
+            const int w = wk.e >> 8;
+            const size_t i = (size_t)w * A_T + (wk.e & 255);
+            wk.r0 = d.road_off[w]; wk.r1 = d.road_off[w + 1]; wk.b0 = d.blk_off[w]; wk.bb = d.road_bbox[w];
+            wk.ex = d.px[i]; wk.ey = d.py[i]; wk.qw = d.qw[i]; wk.qz = d.qz[i]; wk.st = d.pose_stamp[i];
+        }
+        return wk;
     };
     int skipped = 0;
-    Pose nx{0.f, 0.f, 1.f, 0.f, make_uint4(0u, 0u, 0u, 0u)};
-    if (a_first + wave < a_end) nx = load_pose(a_first + wave);
-    for (int a = a_first + wave; a < a_end; a += 4) {  // wave-uniform
-        const size_t i = (size_t)w * A_T + a;
-        const Pose p = nx;
-        if (a + 4 < a_end) nx = load_pose(a + 4);
+    Work nx = load_work(wave);
+    for (int k = wave; k < per; k += 4) {  // wave-uniform
+        const Work p = nx;
+        nx = load_work(k + 4);
+        if (p.e < 0) continue;  // filler entry (the XCD classes hold different numbers of agents)
+        const int w = p.e >> 8;
+        const size_t i = (size_t)w * A_T + (p.e & 255);
+        const int r0 = p.r0, R = p.r1 - p.r0;
+        const float2 *rxy = d.road_xy + r0;
+        const int NB = (R + GD_LIN_BLK - 1) / GD_LIN_BLK;
+        const float4 *blk = d.road_blk + p.b0;
+        const float4 bb = p.bb;  // out of reach of every road: farther than the radius (plus rounding) from the box around the world's roads
         const float ex = p.ex, ey = p.ey;
         const float iw = p.qw, iz = -p.qz;  // the INVERSE rotation
         // rows already written for exactly this pose (and these roads: the stamp is cleared whenever the world is rebuilt)
@@ -243,9 +247,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GD_LIN_WPE)
 
 }  // namespace
 
-void launch_map_obs_linear(const DevSim &d, hipStream_t st) {
-    if (d.lin_group_count == 0) return;
-    const dim3 grid(d.lin_group_count);
+void launch_map_obs_linear(const DevSim &d0, hipStream_t st, bool move) {
+    // A step pass takes the list without the agents that never move (`Static`: their rows were written by the last reset pass,
+    // which follows every rebuild, and their stamps would only confirm it); every other pass takes every live agent.
+    DevSim d = d0;
+    if (move && d.pose_skip != 0 && d.lin_dyn_off == 0) {
+        d.lin_list = d.lin_list_dyn;
+        d.lin_blocks = d.lin_blocks_dyn;
+    }
+    if (d.lin_blocks == 0) return;
+    const dim3 grid(d.lin_blocks);
     if (d.pack != nullptr) {
         if (d.A == 64) hipLaunchKernelGGL((k_map_obs_linear<64, true>), grid, dim3(256), 0, st, d);
         else hipLaunchKernelGGL((k_map_obs_linear<128, true>), grid, dim3(256), 0, st, d);
