@@ -912,6 +912,7 @@ struct gd_sim {
     // *any_reset is set, so a step without finished worlds costs three empty launches and no host sync.
     void reset_flagged(bool gated) {
         d.gate_any = gated ? 1 : 0;
+        if (!gated) full_pass_next = false;  // (an ungated reset pass visits every live agent: nothing is owed any more)
         try {
             launch(gd::KERNEL_RESET, false);
             run_rest(false);
@@ -1472,7 +1473,8 @@ int gd_debug_set_state(gd_sim *s, const float *in) {
         }
         for (size_t i = 0; i < WA; i++) iplane[i] = in[i * 11 + 10] != 0.f;
         HIP_CHECK(hipMemcpy(s->d.collided, iplane.data(), WA * 4, hipMemcpyHostToDevice));
-        s->full_pass_next = true;
+        // agents that never move are not on the linear scan's step-pass list: the next road pass must visit them all the same
+        s->full_pass_next = s->params.roadObservationAlgorithm != GD_ROADS_K_NEAREST && s->d.lin_on != 0;
     });
 }
 

@@ -405,3 +405,35 @@ def test_partner_rows_beyond_the_worlds_agents_are_written_by_reset_passes_only(
     orc.reset([])
     P.compare_obs(gpu, orc, atol=P.FREE_OBS_ATOL, names=["partner_observations_tensor"])
     gpu.close()
+
+
+def test_a_static_agent_moved_from_outside_is_visited_by_the_next_step(monkeypatch):
+    """Step passes of the linear scan leave out the agents that never move (`Static`).  gd_debug_set_state can move one all the
+    same: the road pass of the NEXT step -- a step, not a reset pass -- must then visit every live agent (engine.cpp
+    full_pass_next), and the step after that is back on the captured graph."""
+    import torch
+    scenes = [TEST_JSON, SCENE_407]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        skip = P.make_gpu_sim(scenes, max_agents=128, **PPO_DEFAULT)
+        monkeypatch.setenv("GPUDRIVE_NO_POSE_SKIP", "1")
+        plain = P.make_gpu_sim(scenes, max_agents=128, **PPO_DEFAULT)
+        monkeypatch.delenv("GPUDRIVE_NO_POSE_SKIP")
+        resp = RC.as_np(skip.response_type_tensor())[..., 0]
+        n = RC.as_np(skip.shape_tensor())[:, 0]
+        w, a = [(w, a) for w in range(2) for a in range(n[w]) if resp[w, a] == 2][0]
+        rng = np.random.default_rng(1)
+        for step in range(8):
+            if step == 3:
+                st = skip.debug_get_state()
+                st[w, a, 0] += 12.0
+                st[w, a, 1] -= 7.0
+                for s in (skip, plain):
+                    s.debug_set_state(st)
+            act = P.random_actions(rng, 2, 128, 0)
+            for s in (skip, plain):
+                RC.write_actions(s, act)
+                s.step()
+            assert np.array_equal(_bits(skip.agent_roadmap_tensor()), _bits(plain.agent_roadmap_tensor())), "step %d" % (step + 1)
+        assert skip.stat(0) >= 5, "the steps around the full pass should have been graph replays"
+        skip.close()
+        plain.close()
