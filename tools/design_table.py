@@ -18,8 +18,8 @@ C, _ = load("r04_bench_driver_command.json")
 ROWS = [("synthetic exact-64, R = 4096 (**primary**)", "synthetic", "k-NN, reference order"),
         ("same scenes", "synthetic_linear", "linear (callers' default)"),
         ("same scenes", "synthetic_set", "k-NN, set order"),
-        ("same scenes, learner loop", "rl_loop", "reference order + second-pass pack"),
-        ("same scenes, learner loop", "rl_loop_set", "set order + direct pack"),
+        ("same scenes, learner loop", "rl_loop", "reference order + pack written by the step"),
+        ("same scenes, learner loop", "rl_loop_set", "set order + pack written by the step"),
         ("same generator, 128 slots, all live", "synthetic_128", "k-NN, reference order"),
         ("Waymo tiles (35,489 live agents)", "waymo", "k-NN, reference order"),
         ("Waymo tiles", "waymo_linear", "linear"),
