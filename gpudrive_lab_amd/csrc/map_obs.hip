@@ -527,6 +527,8 @@ __global__ __launch_bounds__(256) void k_map_rows(DevSim d) {
         s_on[al] = on ? 1 : 0;
         if (a0 + al < agents && cnt >= 0 && same) atomicAdd(d.stat_skipped + (blockIdx.x & (GD_SKIP_SLOTS - 1)), 1ull);
     }
+    // nothing to write for any agent of this workgroup (padding slots, agents that did not move): no gathers, no rows
+    if (__syncthreads_or(on ? 1 : 0) == 0) return;
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int q = qf + u;
