@@ -338,11 +338,18 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        for (int eb = 0; eb < n + R; eb += 64) {  // uniform trip count: the ballot below needs every lane
+        // An agent farther from the box around its world's roads than the rays reach plus the largest road's bounding radius can
+        // hit no road: only the agents are looked at (an object that is not valid at t = 0 sits ten kilometres from the map, a
+        // finished one at the padding position: four agents in five on the Waymo tiles, nine entity batches each instead of one).
+        const float4 bb = d.road_bbox[w];
+        const float far = 200.f + d.road_rbmax[w] + 1.f;
+        const float dxo = fmaxf(fmaxf(bb.x - ox, ox - bb.z), 0.f), dyo = fmaxf(fmaxf(bb.y - oy, oy - bb.w), 0.f);
+        const int e_end = (R > 0 && !(dxo * dxo + dyo * dyo > far * far)) ? n + R : n;  // (NaN poses look at everything)
+        for (int eb = 0; eb < e_end; eb += 64) {  // uniform trip count: the ballot below needs every lane
             const int e = eb + lane;
             float cx = 0.f, cy = 0.f, hx = 0.f, hy = 0.f, zlo = 1.f, zhi = 0.f;
             Quat q{1.f, 0.f, 0.f, 0.f};
-            bool valid = e < n + R && e != a;
+            bool valid = e < e_end && e != a;
             if (valid && e < n) {
                 const size_t oi = (size_t)w * A_T + e;
                 cx = d.px[oi]; cy = d.py[oi];

@@ -672,6 +672,11 @@ struct gd_sim {
                 bb[w * 4 + 0] = lo_x; bb[w * 4 + 1] = lo_y; bb[w * 4 + 2] = hi_x; bb[w * 4 + 3] = hi_y;
             }
             HIP_CHECK(hipMemcpy(const_cast<float4 *>(d.road_bbox), bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
+            std::vector<float> rbmax(W, 0.f);  // (road_aux: qw qz d0 d1 | d2 type id mapType)
+            for (int w = 0; w < W; w++)
+                for (size_t r = 0; r * 8 < w_aux[w].size(); r++)
+                    rbmax[w] = std::max(rbmax[w], std::sqrt(w_aux[w][r * 8 + 2] * w_aux[w][r * 8 + 2] + w_aux[w][r * 8 + 3] * w_aux[w][r * 8 + 3]));
+            HIP_CHECK(hipMemcpy(const_cast<float *>(d.road_rbmax), rbmax.data(), rbmax.size() * sizeof(float), hipMemcpyHostToDevice));
             // the circle around every GD_LIN_BLK consecutive road points of a world (centre of their bounding box, the largest
             // distance from it to one of them, rounded up)
             std::vector<int32_t> boff(W + 1, 0);
@@ -1094,6 +1099,7 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.rgrid = s->alloc_internal<gd::GridHdr>(W);
         d.knn_prev = s->alloc_internal<float4>(WA);
         d.road_bbox = s->alloc_internal<float4>(W);
+        d.road_rbmax = s->alloc_internal<float>(W);
         d.lin_apw = 2;
         if (const char *e = std::getenv("GPUDRIVE_LIN_AGENTS_PER_WAVE")) d.lin_apw = std::min(A / 4, std::max(1, std::atoi(e)));
         // worst case: every class as long as the longest one, which holds at most W / 8 + a few worlds' agents

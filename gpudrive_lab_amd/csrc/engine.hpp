@@ -165,6 +165,7 @@ struct DevSim {
     uint32_t *rk_words;    // [W][A][NCH] candidate bits of 32 roads, one row per agent (k_knn_scan -> k_knn_rank)
     float *rk_tl;          // [W][A] the last K-th key of the checkpoint set in use (scales the ranking buckets)
     const float4 *road_bbox;  // [W] (min x, min y, max x, max y) over the world's roads
+    const float *road_rbmax;  // [W] the largest bounding radius (half diagonal) of a road of the world
     int32_t *rk_n;         // [W][A] candidates | in-radius candidates << 16; 0 = not on the rank path this step; 1 << 30 = too far from every road
     int32_t *rk_fallback;  // [W * A / 32] group of 32 agent slots must be selected by k_map_obs this step
     int32_t *rk_streak;    // [W * A / 32] consecutive selections in which the group needed the fallback: from 3 on the group

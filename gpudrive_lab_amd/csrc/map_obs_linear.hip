@@ -7,7 +7,7 @@
 // The first K roads IN INDEX ORDER within the radius, rows in that order: no heap, no selection -- a prefix scan that stops
 // at K, then 7,200 bytes of rows per agent.  The kernel is what the algorithm is:
 //
-//   * one wave per agent at a time (a workgroup of four waves takes 4 * lin_apw consecutive agent slots of one world).  Roads
+//   * one wave per agent at a time (a workgroup of four waves takes 4 * lin_apw consecutive entries of the agent list).  Roads
 //     follow their polylines in index order, so 16 consecutive roads are a short piece of one polyline: the engine keeps the
 //     circle around every such block (engine.hpp road_blk), and the wave first drops the blocks that cannot hold a road in
 //     reach -- a lane per block, 1024 roads per wave instruction.  On the bench scene 270 of a world's 4096 roads are in
@@ -32,8 +32,10 @@
 // With DevSim::pack set (gd_attach_packed) the wave also -- or only: pack_only -- writes the agent's 200 x 13 normalised road
 // columns of the packed observation (pack_cols.hpp), so that a learner that reads packed_observations() pays no second pass.
 //
-// Algorithmic bytes per agent: 8 B per road scanned until K are found + 16 B of pose + 7,200 B of rows (SURVEY.md 8d's
-// contract counts 36 B for every road of the world once per world instead).  Bound: HBM writes.
+// Algorithmic bytes per world and pass: 8 B per road of the longest prefix any of its agents visits (HBM delivers a world's roads
+// once, the L2 serves its agents) + 16 B of pose + 7,200 B of rows per agent that is rewritten (SURVEY.md 8d's contract counts
+// 36 B for every road of the world instead).  Bound: HBM writes -- and of those, streaming stores are the best form by far
+// (NOTEBOOK.md: plain stores 174 us against 109).
 #include <hip/hip_runtime.h>
 
 #include "engine.hpp"
