@@ -404,9 +404,14 @@ def _bench_workload(name, args, rank, local_rank, world, device):
         extra["k_lidar"] = dict(algorithmic_bytes_per_launch=b, achieved=b / (kt["k_lidar"]["avg_us"] * 1e-6) / 1e9,
                                 frac=b / (kt["k_lidar"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, unit="GB/s")
     if "k_bev" in kt and kt["k_bev"]["avg_us"] > 0:
-        b = 160000.0 * live
-        extra["k_bev"] = dict(algorithmic_bytes_per_launch=b, achieved=b / (kt["k_bev"]["avg_us"] * 1e-6) / 1e9,
-                              frac=b / (kt["k_bev"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, unit="GB/s")
+        # rasters whose agent's surroundings did not change are left in place (k_world_step's dirty flags): the bytes moved are
+        # those of the rasters painted (gd_stat 31: the last launch's count), the reference rewrites every live agent's
+        painted = sim.stat(31)
+        b, ref_b = 160000.0 * painted, 160000.0 * live
+        t = kt["k_bev"]["avg_us"] * 1e-6
+        extra["k_bev"] = dict(algorithmic_bytes_per_launch=b, achieved=b / t / 1e9, frac=b / t / 1e9 / HBM_PEAK_GBS, unit="GB/s",
+                              rasters_painted_last_launch=painted, reference_bytes_per_launch=ref_b,
+                              frac_of_reference_bytes=ref_b / t / 1e9 / HBM_PEAK_GBS)
     if kt["k_world_step"]["avg_us"] > 0:
         # state (40 + 52 + 28) + self / absolute rows 88 + partner rows 36 (A - 1) bytes per live agent; with the
         # partner rows in a kernel of their own (k_partner_rows) each kernel is priced with its own share

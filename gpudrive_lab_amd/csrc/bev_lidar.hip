@@ -3,6 +3,8 @@
 // Parameters.enableLidar).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "engine.hpp"
 #include "gd_math.hpp"
 
@@ -84,28 +86,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(GD_BEV_WAVES
     constexpr int NWV = NT / 64;  // waves
     static_assert(NT >= 128 && NT % 64 == 0, "geometry");
     if (d.gate_any && *d.any_reset == 0) return;  // device-driven reset pass: nothing was flagged this step
-    // one workgroup per live agent (engine: live_list); rows of padding agents are never written (src/level_gen.cpp:308-336)
-    const int wa = d.live_list[blockIdx.x], tid = threadIdx.x;
-    const int w = wa / A_T, a = wa - w * A_T;
-    const int n = d.shape[w * 2 + 0];
+    // The workgroups stride over the list of agents whose raster can have changed (k_bev_list below; every live agent on a reset
+    // pass): a fixed grid of a few workgroups per CU instead of one workgroup per live agent -- a workgroup that only finds out it
+    // has nothing to do still has to be handed its 48 KB of LDS and eight waves first (round 2: 0.68 ms for 30 thousand of them).
+    // Rows of padding agents are never written (src/level_gen.cpp:308-336).
+    const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int r0 = d.road_off[w];
-    const int R = d.road_off[w + 1] - r0;
     const float radius = d.p.observationRadius;
-    const size_t i = (size_t)w * A_T + a;
-
     constexpr int MAXE = K + A_T;  // <= K roads and A_T - 1 partners
     __shared__ __attribute__((aligned(16))) unsigned int s_cells[RES * RES / GD_BEV_BANDS];  // one band of rows, 32-bit cells
     __shared__ BevEnt s_ent[MAXE];
     __shared__ int s_wcnt[NWV];
     __shared__ int s_ne;
+    for (int c = tid; c < RES * RES / GD_BEV_BANDS; c += NT) s_cells[c] = 0u;  // (every band is zeroed again on its way out)
+    __shared__ int s_item;
+    const int items = d.bev_count[0];
+    // (the next unclaimed item, not a stride: rasters cost between a few and a few hundred painted cells each)
+#pragma clang loop unroll(disable)
+    for (int item = blockIdx.x;;) {
+    if (item >= items) break;
+    const int wa = d.bev_list[item];
+    const int w = wa / A_T, a = wa - w * A_T;
+    const int n = d.shape[w * 2 + 0];
+    const int r0 = d.road_off[w];
+    const int R = d.road_off[w + 1] - r0;
+    const size_t i = (size_t)w * A_T + a;
 
     BEV_STAMP(t_begin);
     const float ex = d.px[i], ey = d.py[i];
     const Quat rot = quat_from_wz(d.qw[i], d.qz[i]);
     const Quat inv = quat_inv(rot);
-
-    for (int c = tid; c < RES * RES / GD_BEV_BANDS; c += NT) s_cells[c] = 0u;
 
     // ---- roads: first K in-radius in road order (src/sim.cpp:484-523) ----
     int count = 0;
@@ -213,13 +223,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(GD_BEV_WAVES
         }
         __syncthreads();
     }
+    if (tid == 0) s_item = (int)gridDim.x + atomicAdd(d.bev_count + 1, 1);
+    __syncthreads();
+    item = s_item;
+    }  // (the list)
 #ifdef GD_STAMPS
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (tid == 0 && wg < 8192) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         unsigned long long *o = g_bev_stamps[wg];
-        o[0] = t_end - t_begin; o[1] = t_roads - t_begin; o[2] = t_ents - t_roads; o[3] = t_end - t_ents; o[4] = 0;
-        o[5] = 0; o[6] = (unsigned long long)ne; o[7] = (unsigned long long)R;
+        o[0] = t_end; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0;
+        o[5] = 0; o[6] = (unsigned long long)items; o[7] = 0;  // (per-phase stamps were per workgroup = per agent before the list)
     }
 #endif
 }
@@ -505,11 +519,35 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
     }
 }
 
+// live_list compacted to the agents whose bev_dirty flag is set (the order inside the list is the order the workgroups' atomic
+// adds arrive in: it decides nothing but who rasterises whom)
+__global__ __launch_bounds__(1024) void k_bev_list(DevSim d) {
+    if (d.gate_any && *d.any_reset == 0) return;
+    __shared__ int s_cnt[16], s_base;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int idx = blockIdx.x * 1024 + tid;
+    const int wa = idx < d.live_count ? d.live_list[idx] : 0;
+    const bool on = idx < d.live_count && d.bev_dirty[wa] != 0;
+    const unsigned long long b = __ballot(on);
+    if (lane == 0) s_cnt[wave] = __popcll(b);
+    __syncthreads();
+    if (tid == 0) {
+        int total = 0;
+        for (int v = 0; v < 16; v++) { const int c = s_cnt[v]; s_cnt[v] = total; total += c; }
+        s_base = total ? atomicAdd(d.bev_count, total) : 0;
+    }
+    __syncthreads();
+    if (on) d.bev_list[s_base + s_cnt[wave] + __popcll(b & ((1ull << lane) - 1ull))] = wa;
+}
+
 }  // namespace
 
 void launch_bev(const DevSim &d, hipStream_t st) {
     if (d.live_count == 0) return;
-    const dim3 grid(d.live_count);
+    (void)hipMemsetAsync(d.bev_count, 0, 2 * sizeof(int32_t), st);  // [0] the list's length, [1] items claimed beyond the grid's first
+    hipLaunchKernelGGL(k_bev_list, dim3((d.live_count + 1023) / 1024), dim3(1024), 0, st, d);
+    // a fixed grid: up to 12 workgroups' worth of agents per CU slot (three 512-thread workgroups fit a CU), fewer for small batches
+    const dim3 grid((unsigned int)std::min(d.live_count, 3 * 256 * 4));
     constexpr int NT = 512;  // 8 waves x 25 grid rows (measured: 256 threads 3.5 ms, 512 3.1 ms, 640 5.4 ms)
     if (d.A == 64) hipLaunchKernelGGL((k_bev<64, NT>), grid, dim3(NT), 0, st, d);
     else hipLaunchKernelGGL((k_bev<128, NT>), grid, dim3(NT), 0, st, d);

@@ -306,16 +306,19 @@ struct gd_sim {
     }
 
     void step() {
-        if (full_pass_next) {  // (gd_debug_set_state moved agents behind the engine's back: nobody is left out of this step's road pass)
+        if (full_pass_next) {  // (gd_debug_set_state moved agents behind the engine's back: nobody is left out of this step's road pass / rasters)
             full_pass_next = false;
             d.lin_dyn_off = 1;
+            d.bev_all_dirty = 1;
             try {
                 run_rest(true);
             } catch (...) {
                 d.lin_dyn_off = 0;
+                d.bev_all_dirty = 0;
                 throw;
             }
             d.lin_dyn_off = 0;
+            d.bev_all_dirty = 0;
             stat_plain_steps++;
             return;
         }
@@ -710,6 +713,7 @@ struct gd_sim {
             d.road_blk = static_cast<const float4 *>(d_road_blk);
             // no row written before this call describes the worlds as they are now (roads, agent slots): every pose stamp dies
             HIP_CHECK(hipMemsetAsync(d.pose_stamp, 0xff, sizeof(uint4) * static_cast<size_t>(W) * A, stream));
+            HIP_CHECK(hipMemsetAsync(d.bev_dirty, 1, sizeof(int32_t) * static_cast<size_t>(W) * A, stream));
         }
         if (rk_possible) {
             // Which worlds take the rank replay (neither path changes a result).  Measured at 64 agent slots (road
@@ -1100,6 +1104,11 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.knn_prev = s->alloc_internal<float4>(WA);
         d.road_bbox = s->alloc_internal<float4>(W);
         d.road_rbmax = s->alloc_internal<float>(W);
+        d.bev_dirty = s->alloc_internal<int32_t>(WA);
+        d.bev_list = s->alloc_internal<int32_t>(WA);
+        d.bev_count = s->alloc_internal<int32_t>(2);
+        d.bev_all_dirty = 0;
+        HIP_CHECK(hipMemset(d.bev_dirty, 1, sizeof(int32_t) * WA));  // (non-zero: everything is to be rasterised until k_world_step says otherwise)
         d.lin_apw = 2;
         if (const char *e = std::getenv("GPUDRIVE_LIN_AGENTS_PER_WAVE")) d.lin_apw = std::min(A / 4, std::max(1, std::atoi(e)));
         // worst case: every class as long as the longest one, which holds at most W / 8 + a few worlds' agents
@@ -1318,6 +1327,7 @@ int gd_attach_bev(gd_sim *s, float *bev) {
         s->drop_graph();
         s->exported[GD_T_BEV] = bev;
         s->d.bev = bev;
+        HIP_CHECK(hipMemsetAsync(s->d.bev_dirty, 1, sizeof(int32_t) * static_cast<size_t>(s->W) * s->A, s->stream));
         if (!s->params.disableClassicalObs) s->launch(gd::KERNEL_BEV, false);  // the rasters of the current state
     });
 }
@@ -1354,6 +1364,14 @@ int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
         for (unsigned long long x : v) sum += x;
         *out = static_cast<int64_t>(sum) + s->host_skipped;
         s->host_skipped = 0;
+        return GD_OK;
+    }
+    if (s && out && which == 31) {  // BEV rasters painted by the last pass that rasterised (bev_lidar.hip k_bev_list's count)
+        int32_t c = 0;
+        (void)hipStreamSynchronize(s->stream);
+        if (hipMemcpy(&c, s->d.bev_count, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(GD_ERR_DEVICE, "gd_stat: reading the raster count failed");
+        *out = c;
         return GD_OK;
     }
     if (s && out && which == 21) {  // bounds audit of the rank path (engine.hpp GD_RANK_AUDIT): violations since the buffers exist
@@ -1480,7 +1498,8 @@ int gd_debug_set_state(gd_sim *s, const float *in) {
         for (size_t i = 0; i < WA; i++) iplane[i] = in[i * 11 + 10] != 0.f;
         HIP_CHECK(hipMemcpy(s->d.collided, iplane.data(), WA * 4, hipMemcpyHostToDevice));
         // agents that never move are not on the linear scan's step-pass list: the next road pass must visit them all the same
-        s->full_pass_next = s->params.roadObservationAlgorithm != GD_ROADS_K_NEAREST && s->d.lin_on != 0;
+        // ... and k_world_step's "who moved" (the BEV's dirty flags) compares the poses before and after its own movement only
+        s->full_pass_next = (s->params.roadObservationAlgorithm != GD_ROADS_K_NEAREST && s->d.lin_on != 0) || s->d.bev != nullptr;
     });
 }
 

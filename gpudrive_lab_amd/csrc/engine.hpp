@@ -131,6 +131,14 @@ struct DevSim {
     // x = 0xffffffff: none (set for every agent whenever worlds are rebuilt -- roads or agent slots may have changed)
     uint4 *pose_stamp;             // [W][A]
     int pose_skip;                 // 0: GPUDRIVE_NO_POSE_SKIP=1 -- every live agent's rows are rewritten on every step
+    // BEV rasters (bev_lidar.hip) are rewritten only for agents whose picture can have changed: the agent moved, or an agent that
+    // moved is (or was) within the radius of it.  k_world_step decides (bev_dirty, 1 = rewrite; every live agent on reset passes,
+    // with GPUDRIVE_NO_POSE_SKIP=1 and when bev_all_dirty is set), k_bev_list compacts live_list to the dirty agents, k_bev's
+    // workgroups stride over that list.
+    int32_t *bev_dirty;   // [W][A]
+    int32_t *bev_list;    // [W * A] (world * A + agent) of the agents to rasterise in this pass
+    int32_t *bev_count;   // [1]
+    int bev_all_dirty;
     // packed observation written where the raw rows are produced (gd_attach_packed): [W][A][6 + (A-1)*6 + K*13], or null.
     // pack_only: the raw partner and road tensors of live agents are NOT written any more (a learner that only reads the
     // packed tensor; the padding agents' rows, written when the worlds are built, stay valid)

@@ -357,6 +357,8 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     __shared__ float s_obb[14][A_T];
     __shared__ int s_hit[A_T];  // collision flags found by the threads sharing an agent
     __shared__ float s_self[A_T * 8];  // the self-observation rows (packed_head reads them)
+    __shared__ float s_opx[A_T], s_opy[A_T];  // positions before the movement, and who moved at all (the BEV's dirty flags)
+    __shared__ int s_moved[A_T];
     constexpr int SVCAP = 6 * STEP_THREADS;  // candidates looked at per trip of the road-box phase (six per thread)
     __shared__ unsigned int s_sv[SVCAP];  // road boxes that passed the cull: agent | local box index << 8 | entity type << 28
     __shared__ int s_nsv[2];
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     STEP_PHASE(0);
+    const float old_px = b.px, old_py = b.py, old_qw = b.qw, old_qz = b.qz;  // (what the BEV's "did anything move" compares with)
     // ---- movementSystem, src/sim.cpp:294-383 ----
     if (MOVE && live) {
         if (collided) {
@@ -462,6 +465,11 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         s_id[a] = d.agent_id[i];
         s_rad[a] = sqrtf(sc0 * sc0 + sc1 * sc1);
         s_flags[a] = (active ? 1 : 0) | (resp == RESP_Static ? 2 : 0);
+        if (d.bev != nullptr) {
+            s_opx[a] = old_px; s_opy[a] = old_py;
+            s_moved[a] = (__float_as_uint(old_px) != __float_as_uint(b.px) || __float_as_uint(old_py) != __float_as_uint(b.py) ||
+                          __float_as_uint(old_qw) != __float_as_uint(b.qw) || __float_as_uint(old_qz) != __float_as_uint(b.qz)) ? 1 : 0;
+        }
         if (active) {
             const Obb o = obb_from_yaw(b.px, b.py, theta, sc0, sc1);
             const float *of = reinterpret_cast<const float *>(&o);
@@ -471,6 +479,22 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     }
     __syncthreads();
     STEP_PHASE(2);
+    // ---- which BEV rasters can have changed (collectBevObservationsSystem paints the in-radius roads and partners around the
+    // agent, src/sim.cpp:462-555): the agent's own pose changed, or an agent whose pose changed is within the radius of it now or
+    // was before it moved (a little more than the radius: whoever is marked without need is merely rasterised again) ----
+    if (d.bev != nullptr && live) {
+        int dirty = (!MOVE || d.pose_skip == 0 || d.bev_all_dirty != 0 || s_moved[a] != 0) ? 1 : 0;
+        if (!dirty) {
+            const float rr = d.p.observationRadius * 1.001f + 0.05f, r2 = rr * rr;
+            const float mx = s_px[a], my = s_py[a];  // (this agent did not move: its old position is its new one)
+            for (int j = 0; j < n; j++) {
+                if (s_moved[j] == 0) continue;
+                const float dx = s_px[j] - mx, dy = s_py[j] - my, ox = s_opx[j] - mx, oy = s_opy[j] - my;
+                if (!(dx * dx + dy * dy > r2) || !(ox * ox + oy * oy > r2)) { dirty = 1; break; }
+            }
+        }
+        d.bev_dirty[i] = dirty;
+    }
 
     // ---- collisionDetectionSystem over broadphase candidates, src/sim.cpp:628-747, 792-801 ----
     // All STEP_THREADS threads work here: P = STEP_THREADS / A threads per agent share its candidate

@@ -228,7 +228,10 @@ int gd_attach_bev(gd_sim *sim, float *bev);
  * reference-order road selection takes the rank replay (0 / 1).  Developer builds (tools/build_expt.sh) add 8 = the most
  * crowded ranking bucket (-DGD_DIAG with GPUDRIVE_RANK_DBG=9) and 10..17 = clock ticks per phase of k_knn_rank, then
  * 18..20 = k_knn_replay's rounds of its first wave / candidates beyond K / inserts (-DGD_CLOCKS; tools/rank_spikes.py),
- * all since the last read; otherwise GD_ERR_INVALID. */
+ * all since the last read.  Every build: 21 = accesses the rank replay's bounds audit found out of range since its buffers
+ * exist (must stay 0), 30 = agents whose road rows were left in place because their pose bits had not changed, since the last
+ * read, 31 = BEV rasters painted by the last pass that rasterised (the others could not have changed and were left in
+ * place).  Otherwise GD_ERR_INVALID. */
 int gd_stat(gd_sim *sim, int32_t which, int64_t *out);
 
 /* Timing hooks for the bench: HIP events around the named kernel on the engine's stream (a fixed ring of event pairs,

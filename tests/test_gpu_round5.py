@@ -437,3 +437,59 @@ def test_a_static_agent_moved_from_outside_is_visited_by_the_next_step(monkeypat
         assert skip.stat(0) >= 5, "the steps around the full pass should have been graph replays"
         skip.close()
         plain.close()
+
+
+def test_bev_rasters_left_in_place_are_the_rasters_a_repaint_would_produce(monkeypatch, oracle_mod):
+    """k_world_step marks the agents whose BEV raster can have changed (own pose bits changed, or an agent that moved is or was
+    within reach) and k_bev repaints only those.  Two simulators on Waymo scenes under the default init rules (parked cars
+    Static), one with GPUDRIVE_NO_POSE_SKIP=1 (every live agent repainted every step), same actions through a partial reset, a
+    teleport from outside the engine and a set_maps: the same bytes at every step, rasters must really have been left alone,
+    and the skipping simulator still matches the oracle's rasters at the end."""
+    kw = dict(PPO_DEFAULT, roadObservationAlgorithm=1)
+    scenes = [TEST_JSON, SCENE_407, SCENE_4, SCENE_407]
+    skip = P.make_gpu_sim(scenes, max_agents=128, enable_bev=True, **kw)
+    monkeypatch.setenv("GPUDRIVE_NO_POSE_SKIP", "1")
+    plain = P.make_gpu_sim(scenes, max_agents=128, enable_bev=True, **kw)
+    monkeypatch.delenv("GPUDRIVE_NO_POSE_SKIP")
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=128, enableBev=1, **kw)
+    rng = np.random.default_rng(16)
+    live = RC.as_np(skip.shape_tensor())[:, 0]
+    painted_total = 0
+
+    def same(step):
+        a, b = RC.as_np(skip.bev_observation_tensor()), RC.as_np(plain.bev_observation_tensor())
+        for w in range(len(scenes)):
+            n = int(RC.as_np(skip.shape_tensor())[w, 0])
+            if not np.array_equal(a[w, :n].view(np.uint32), b[w, :n].view(np.uint32)):
+                bad = np.argwhere(a[w, :n] != b[w, :n])
+                raise AssertionError("step %d world %d: %d cells differ, first at %s" % (step, w, len(bad), bad[0]))
+
+    same(0)
+    for step in range(40):
+        act = P.random_actions(rng, len(scenes), 128, 0)
+        act[:, 5:] = 0.0  # most agents stand still: their neighbourhoods are the ones that may be left alone
+        for s in (skip, plain):
+            RC.write_actions(s, act)
+            s.step()
+        if step < 20:
+            np.copyto(orc.action_tensor(), act)
+            orc.step()
+        painted_total += skip.stat(31)
+        if step == 12:
+            for s in (skip, plain, orc):
+                s.reset([0, 3])
+        if step == 19:
+            assert P.compare_bev(skip, orc) > 0.001   # (the oracle has no debug_set_state: it leaves here)
+        if step == 20:
+            st = skip.debug_get_state()
+            st[:, 1:3, 0] += 8.0
+            for s in (skip, plain):
+                s.debug_set_state(st)
+                s.reset([])
+        if step == 30:
+            for s in (skip, plain):
+                s.set_maps(scenes[::-1])
+        same(step + 1)
+    assert 0 < painted_total < 40 * int(live.sum()), "rasters were repainted %d times for %d live agents" % (painted_total, live.sum())
+    skip.close()
+    plain.close()
