@@ -239,8 +239,7 @@ template <int A_T>
 __device__ __forceinline__ void partner_rows(const DevSim &d, int w, int n, int a, const float *s_px, const float *s_py,
                                              const float *s_qw, const float *s_qz, const float *s_speed, const float *s_len,
                                              const float *s_wid, const float *s_hgt, const int *s_etype, const int *s_id,
-                                             bool write_const) {
-    __shared__ __attribute__((aligned(16))) float s_rows[STEP_THREADS * 9];
+                                             bool write_const, float *s_rows) {  // s_rows: STEP_THREADS * 9 floats of LDS, 16-byte aligned
     float *base = d.partner + (size_t)w * A_T * (A_T - 1) * 9;
     typedef float f4 __attribute__((ext_vector_type(4)));
     if (!write_const && n < A_T) {
@@ -357,10 +356,18 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     __shared__ float s_obb[14][A_T];
     __shared__ int s_hit[A_T];  // collision flags found by the threads sharing an agent
     __shared__ float s_self[A_T * 8];  // the self-observation rows (packed_head reads them)
-    __shared__ float s_opx[A_T], s_opy[A_T];  // positions before the movement, and who moved at all (the BEV's dirty flags)
-    __shared__ int s_moved[A_T];
-    constexpr int SVCAP = 6 * STEP_THREADS;  // candidates looked at per trip of the road-box phase (six per thread)
-    __shared__ unsigned int s_sv[SVCAP];  // road boxes that passed the cull: agent | local box index << 8 | entity type << 28
+    // One staging buffer for three phases that follow each other with workgroup barriers between them: the positions before the
+    // movement and who moved at all (the BEV's dirty flags, right after the publish), the road boxes that passed the cull
+    // (agent | local box index << 8 | entity type << 28), and the partner rows on their way out.  (Each with LDS of its own,
+    // k_world_step<128> took 42,000 bytes: three workgroups per CU instead of four, a second generation for 1024 worlds.)
+    __shared__ __attribute__((aligned(16))) float s_stage[STEP_THREADS * 9];
+    float *const s_opx = s_stage, *const s_opy = s_stage + A_T;
+    unsigned long long *const s_moved = reinterpret_cast<unsigned long long *>(s_stage + 2 * A_T);  // a bit per agent slot
+    // candidates looked at per trip of the road-box phase: six per thread (2,285 (agent, candidate) items per world on the bench
+    // scene with 128 slots are two trips; with eight or nine per thread and one trip the kernel took the same 185 us)
+    constexpr int SVCAP = 6 * STEP_THREADS;
+    static_assert(SVCAP <= STEP_THREADS * 9 && 3 * A_T <= STEP_THREADS * 9, "the staging buffer holds each of its tenants");
+    unsigned int *const s_sv = reinterpret_cast<unsigned int *>(s_stage);
     __shared__ int s_nsv[2];
     __shared__ int s_c0[A_T], s_coff[A_T], s_wtot[A_T / 64];  // road-box candidates: first entry, offset in the world's item list, per-wave totals
 
@@ -396,7 +403,6 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     STEP_PHASE(0);
-    const float old_px = b.px, old_py = b.py, old_qw = b.qw, old_qz = b.qz;  // (what the BEV's "did anything move" compares with)
     // ---- movementSystem, src/sim.cpp:294-383 ----
     if (MOVE && live) {
         if (collided) {
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
 
     STEP_PHASE(1);
     // ---- publish per-agent geometry for the pair phases ----
-    bool active = false;
+    bool active = false, moved = false;
     float theta = 0.f;  // quat_to_yaw of the pose after the movement: the agent's box and its absolute row both need it
     if (a < A_T) s_hit[a] = 0;
     if (live) {
@@ -466,9 +472,11 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         s_rad[a] = sqrtf(sc0 * sc0 + sc1 * sc1);
         s_flags[a] = (active ? 1 : 0) | (resp == RESP_Static ? 2 : 0);
         if (d.bev != nullptr) {
+            // (the pose before the movement is still what the state arrays hold: they are written back further down)
+            const float old_px = d.px[i], old_py = d.py[i], old_qw = d.qw[i], old_qz = d.qz[i];
             s_opx[a] = old_px; s_opy[a] = old_py;
-            s_moved[a] = (__float_as_uint(old_px) != __float_as_uint(b.px) || __float_as_uint(old_py) != __float_as_uint(b.py) ||
-                          __float_as_uint(old_qw) != __float_as_uint(b.qw) || __float_as_uint(old_qz) != __float_as_uint(b.qz)) ? 1 : 0;
+            moved = __float_as_uint(old_px) != __float_as_uint(b.px) || __float_as_uint(old_py) != __float_as_uint(b.py) ||
+                    __float_as_uint(old_qw) != __float_as_uint(b.qw) || __float_as_uint(old_qz) != __float_as_uint(b.qz);
         }
         if (active) {
             const Obb o = obb_from_yaw(b.px, b.py, theta, sc0, sc1);
@@ -477,20 +485,27 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
             for (int k = 0; k < 14; k++) s_obb[k][a] = of[k];
         }
     }
+    if (d.bev != nullptr && a < A_T) {  // (whole waves: the agents that moved, a bit per agent slot)
+        const unsigned long long mv = __ballot(moved);
+        if ((a & 63) == 0) s_moved[a >> 6] = mv;
+    }
     __syncthreads();
     STEP_PHASE(2);
     // ---- which BEV rasters can have changed (collectBevObservationsSystem paints the in-radius roads and partners around the
     // agent, src/sim.cpp:462-555): the agent's own pose changed, or an agent whose pose changed is within the radius of it now or
     // was before it moved (a little more than the radius: whoever is marked without need is merely rasterised again) ----
     if (d.bev != nullptr && live) {
-        int dirty = (!MOVE || d.pose_skip == 0 || d.bev_all_dirty != 0 || s_moved[a] != 0) ? 1 : 0;
+        int dirty = (!MOVE || d.pose_skip == 0 || d.bev_all_dirty != 0 || moved) ? 1 : 0;
         if (!dirty) {
             const float rr = d.p.observationRadius * 1.001f + 0.05f, r2 = rr * rr;
             const float mx = s_px[a], my = s_py[a];  // (this agent did not move: its old position is its new one)
-            for (int j = 0; j < n; j++) {
-                if (s_moved[j] == 0) continue;
-                const float dx = s_px[j] - mx, dy = s_py[j] - my, ox = s_opx[j] - mx, oy = s_opy[j] - my;
-                if (!(dx * dx + dy * dy > r2) || !(ox * ox + oy * oy > r2)) { dirty = 1; break; }
+#pragma unroll
+            for (int h = 0; h < A_T / 64; h++) {
+                for (unsigned long long m = s_moved[h]; m != 0ull && !dirty; m &= m - 1ull) {
+                    const int j = h * 64 + __ffsll((long long)m) - 1;
+                    const float dx = s_px[j] - mx, dy = s_py[j] - my, ox = s_opx[j] - mx, oy = s_opy[j] - my;
+                    if (!(dx * dx + dy * dy > r2) || !(ox * ox + oy * oy > r2)) dirty = 1;
+                }
             }
         }
         d.bev_dirty[i] = dirty;
@@ -705,7 +720,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     STEP_PHASE(5);
     // ---- collectPartnerObsSystem, :188-240: here, or in k_partner_rows on a stream of its own beside the road kernels ----
     if (!d.p.disableClassicalObs && !d.split_partner && !d.pack_only)
-        partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id, !MOVE || d.pose_skip == 0);
+        partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id, !MOVE || d.pose_skip == 0, s_stage);
     if (d.pack != nullptr && !d.p.disableClassicalObs) {
         __syncthreads();  // the agent threads' self columns
         packed_head<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_self);
@@ -734,7 +749,8 @@ __global__ __launch_bounds__(STEP_THREADS) void k_partner_rows(DevSim d) {
         s_id[a] = d.agent_id[i];
     }
     __syncthreads();
-    partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id, true);
+    __shared__ __attribute__((aligned(16))) float s_rows[STEP_THREADS * 9];
+    partner_rows<A_T>(d, w, n, a, s_px, s_py, s_qw, s_qz, s_speed, s_len, s_wid, s_hgt, s_etype, s_id, true, s_rows);
 }
 
 }  // namespace
