@@ -400,9 +400,13 @@ def _bench_workload(name, args, rank, local_rank, world, device):
     # the other kernels with a SURVEY 8d byte count, same steps
     extra = {}
     if "k_lidar" in kt and kt["k_lidar"]["avg_us"] > 0:
-        b = 2400.0 * live + 36.0 * roads
-        extra["k_lidar"] = dict(algorithmic_bytes_per_launch=b, achieved=b / (kt["k_lidar"]["avg_us"] * 1e-6) / 1e9,
-                                frac=b / (kt["k_lidar"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, unit="GB/s")
+        # returns of agents around whom nothing changed are left in place (k_world_step's flags; gd_stat 44: the last launch's count)
+        traced = sim.stat(44)
+        b, ref_b = 2400.0 * traced + 36.0 * roads, 2400.0 * live + 36.0 * roads
+        t = kt["k_lidar"]["avg_us"] * 1e-6
+        extra["k_lidar"] = dict(algorithmic_bytes_per_launch=b, achieved=b / t / 1e9, frac=b / t / 1e9 / HBM_PEAK_GBS, unit="GB/s",
+                                agents_traced_last_launch=traced, reference_bytes_per_launch=ref_b,
+                                frac_of_reference_bytes=ref_b / t / 1e9 / HBM_PEAK_GBS)
     if "k_bev" in kt and kt["k_bev"]["avg_us"] > 0:
         # rasters whose agent's surroundings did not change are left in place (k_world_step's dirty flags): the bytes moved are
         # those of the rasters painted (gd_stat 31: the last launch's count), the reference rewrites every live agent's

@@ -332,6 +332,9 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
     const int a_end = min(n, (int)(blockIdx.y + 1) * GROUP);
     for (int a = blockIdx.y * GROUP + wave; a < a_end; a += 4) {
         const size_t i = (size_t)w * A_T + a;
+        // returns that cannot have changed since they were last traced are left in place (k_world_step's verdict: engine.hpp
+        // lidar_dirty; only wave-level synchronisation inside this loop, so a wave may skip an agent on its own)
+        if (d.lidar_dirty[i] == 0) continue;
         const float ox = d.px[i], oy = d.py[i], oz = d.pz[i];
         const Quat rot = quat_from_wz(d.qw[i], d.qz[i]);
         const Quat inv = quat_inv(rot);
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(256) void k_lidar(DevSim d) {
                 o[0] = tt; o[1] = (float)type; o[2] = tt * s_x[wave][idx]; o[3] = tt * s_y[wave][idx];
             }
         }
+        if (lane == 0) d.lidar_head[i] = head_angle;  // (what k_world_step compares the next action row's head angle with)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

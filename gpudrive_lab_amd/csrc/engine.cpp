@@ -714,6 +714,8 @@ struct gd_sim {
             // no row written before this call describes the worlds as they are now (roads, agent slots): every pose stamp dies
             HIP_CHECK(hipMemsetAsync(d.pose_stamp, 0xff, sizeof(uint4) * static_cast<size_t>(W) * A, stream));
             HIP_CHECK(hipMemsetAsync(d.bev_dirty, 1, sizeof(int32_t) * static_cast<size_t>(W) * A, stream));
+            HIP_CHECK(hipMemsetAsync(d.lidar_dirty, 1, sizeof(int32_t) * static_cast<size_t>(W) * A, stream));
+            HIP_CHECK(hipMemsetAsync(d.lidar_head, 0xff, sizeof(float) * static_cast<size_t>(W) * A, stream));
         }
         if (rk_possible) {
             // Which worlds take the rank replay (neither path changes a result).  Measured at 64 agent slots (road
@@ -1109,6 +1111,10 @@ int gd_create(const gd_config *cfg, const gd_params *params, const char *const *
         d.bev_count = s->alloc_internal<int32_t>(2);
         d.bev_all_dirty = 0;
         HIP_CHECK(hipMemset(d.bev_dirty, 1, sizeof(int32_t) * WA));  // (non-zero: everything is to be rasterised until k_world_step says otherwise)
+        d.lidar_dirty = s->alloc_internal<int32_t>(WA);
+        d.lidar_head = s->alloc_internal<float>(WA);
+        HIP_CHECK(hipMemset(d.lidar_dirty, 1, sizeof(int32_t) * WA));
+        HIP_CHECK(hipMemset(d.lidar_head, 0xff, sizeof(float) * WA));
         d.lin_apw = 2;
         if (const char *e = std::getenv("GPUDRIVE_LIN_AGENTS_PER_WAVE")) d.lin_apw = std::min(A / 4, std::max(1, std::atoi(e)));
         // worst case: every class as long as the longest one, which holds at most W / 8 + a few worlds' agents
@@ -1374,6 +1380,18 @@ int gd_stat(gd_sim *s, int32_t which, int64_t *out) {
         *out = c;
         return GD_OK;
     }
+    if (s && out && which == 44) {  // agents whose LiDAR returns the last pass marked for tracing (the others were left in place)
+        std::vector<int32_t> f(static_cast<size_t>(s->W) * s->A), n(static_cast<size_t>(s->W) * 2);
+        (void)hipStreamSynchronize(s->stream);
+        if (hipMemcpy(f.data(), s->d.lidar_dirty, sizeof(int32_t) * f.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(n.data(), s->d.shape, sizeof(int32_t) * n.size(), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(GD_ERR_DEVICE, "gd_stat: reading the LiDAR flags failed");
+        int64_t c = 0;
+        for (int w = 0; w < s->W; w++)
+            for (int a = 0; a < n[static_cast<size_t>(w) * 2] && a < s->A; a++) c += f[static_cast<size_t>(w) * s->A + a] != 0;
+        *out = c;
+        return GD_OK;
+    }
     if (s && out && which == 21) {  // bounds audit of the rank path (engine.hpp GD_RANK_AUDIT): violations since the buffers exist
         *out = 0;
         if (s->rk_alloc) {
@@ -1499,7 +1517,8 @@ int gd_debug_set_state(gd_sim *s, const float *in) {
         HIP_CHECK(hipMemcpy(s->d.collided, iplane.data(), WA * 4, hipMemcpyHostToDevice));
         // agents that never move are not on the linear scan's step-pass list: the next road pass must visit them all the same
         // ... and k_world_step's "who moved" (the BEV's dirty flags) compares the poses before and after its own movement only
-        s->full_pass_next = (s->params.roadObservationAlgorithm != GD_ROADS_K_NEAREST && s->d.lin_on != 0) || s->d.bev != nullptr;
+        s->full_pass_next = (s->params.roadObservationAlgorithm != GD_ROADS_K_NEAREST && s->d.lin_on != 0) || s->d.bev != nullptr ||
+                            (s->d.lidar != nullptr && s->params.enableLidar);
     });
 }
 

@@ -138,7 +138,12 @@ struct DevSim {
     int32_t *bev_dirty;   // [W][A]
     int32_t *bev_list;    // [W * A] (world * A + agent) of the agents to rasterise in this pass
     int32_t *bev_count;   // [1]
-    int bev_all_dirty;
+    int bev_all_dirty;    // (also for the LiDAR flags below)
+    // The same for the LiDAR returns (k_lidar): an agent's rays see the agents within 200 m (+ their bounding radius), the static
+    // roads, and start at its own pose with the head angle of its action row; lidar_head = the head angle its returns were last
+    // traced with (0xffffffff: none).  lidar_dirty is k_world_step's verdict for this step.
+    int32_t *lidar_dirty;  // [W][A]
+    float *lidar_head;     // [W][A]
     // packed observation written where the raw rows are produced (gd_attach_packed): [W][A][6 + (A-1)*6 + K*13], or null.
     // pack_only: the raw partner and road tensors of live agents are NOT written any more (a learner that only reads the
     // packed tensor; the padding agents' rows, written when the worlds are built, stay valid)

@@ -451,6 +451,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
     STEP_PHASE(1);
     // ---- publish per-agent geometry for the pair phases ----
     bool active = false, moved = false;
+    const bool track_moves = d.bev != nullptr || (d.lidar != nullptr && d.p.enableLidar != 0);  // (BEV rasters / LiDAR returns left in place where nothing changed)
     float theta = 0.f;  // quat_to_yaw of the pose after the movement: the agent's box and its absolute row both need it
     if (a < A_T) s_hit[a] = 0;
     if (live) {
@@ -471,11 +472,12 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
         s_id[a] = d.agent_id[i];
         s_rad[a] = sqrtf(sc0 * sc0 + sc1 * sc1);
         s_flags[a] = (active ? 1 : 0) | (resp == RESP_Static ? 2 : 0);
-        if (d.bev != nullptr) {
+        if (track_moves) {
             // (the pose before the movement is still what the state arrays hold: they are written back further down)
-            const float old_px = d.px[i], old_py = d.py[i], old_qw = d.qw[i], old_qz = d.qz[i];
+            const float old_px = d.px[i], old_py = d.py[i], old_pz = d.pz[i], old_qw = d.qw[i], old_qz = d.qz[i];
             s_opx[a] = old_px; s_opy[a] = old_py;
             moved = __float_as_uint(old_px) != __float_as_uint(b.px) || __float_as_uint(old_py) != __float_as_uint(b.py) ||
+                    __float_as_uint(old_pz) != __float_as_uint(b.pz) ||
                     __float_as_uint(old_qw) != __float_as_uint(b.qw) || __float_as_uint(old_qz) != __float_as_uint(b.qz);
         }
         if (active) {
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
             for (int k = 0; k < 14; k++) s_obb[k][a] = of[k];
         }
     }
-    if (d.bev != nullptr && a < A_T) {  // (whole waves: the agents that moved, a bit per agent slot)
+    if (track_moves && a < A_T) {  // (whole waves: the agents that moved, a bit per agent slot)
         const unsigned long long mv = __ballot(moved);
         if ((a & 63) == 0) s_moved[a >> 6] = mv;
     }
@@ -509,6 +511,25 @@ __global__ __launch_bounds__(STEP_THREADS) void k_world_step(DevSim d) {
             }
         }
         d.bev_dirty[i] = dirty;
+    }
+    // ---- the same for the LiDAR returns (lidarSystem, src/sim.cpp:394-460, 895-913): the agent's own pose or the head angle of its
+    // action row changed, or an agent that moved is or was within the rays' 200 m plus its own bounding radius ----
+    if (d.lidar != nullptr && d.p.enableLidar != 0 && live) {
+        const float head = controlled ? d.action[i * 10 + 2] : 0.f;
+        int dirty = (!MOVE || d.pose_skip == 0 || d.bev_all_dirty != 0 || moved || __float_as_uint(head) != __float_as_uint(d.lidar_head[i])) ? 1 : 0;
+        if (!dirty) {
+            const float mx = s_px[a], my = s_py[a];
+#pragma unroll
+            for (int h = 0; h < A_T / 64; h++) {
+                for (unsigned long long m = s_moved[h]; m != 0ull && !dirty; m &= m - 1ull) {
+                    const int j = h * 64 + __ffsll((long long)m) - 1;
+                    const float rr = (200.f + s_rad[j]) * 1.001f + 0.1f, r2 = rr * rr;
+                    const float dx = s_px[j] - mx, dy = s_py[j] - my, ox = s_opx[j] - mx, oy = s_opy[j] - my;
+                    if (!(dx * dx + dy * dy > r2) || !(ox * ox + oy * oy > r2)) dirty = 1;
+                }
+            }
+        }
+        d.lidar_dirty[i] = dirty;
     }
 
     // ---- collisionDetectionSystem over broadphase candidates, src/sim.cpp:628-747, 792-801 ----

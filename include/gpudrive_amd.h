@@ -231,7 +231,7 @@ int gd_attach_bev(gd_sim *sim, float *bev);
  * all since the last read.  Every build: 21 = accesses the rank replay's bounds audit found out of range since its buffers
  * exist (must stay 0), 30 = agents whose road rows were left in place because their pose bits had not changed, since the last
  * read, 31 = BEV rasters painted by the last pass that rasterised (the others could not have changed and were left in
- * place).  Otherwise GD_ERR_INVALID. */
+ * place), 44 = agents whose LiDAR returns the last pass marked for tracing (likewise).  Otherwise GD_ERR_INVALID. */
 int gd_stat(gd_sim *sim, int32_t which, int64_t *out);
 
 /* Timing hooks for the bench: HIP events around the named kernel on the engine's stream (a fixed ring of event pairs,

@@ -493,3 +493,56 @@ def test_bev_rasters_left_in_place_are_the_rasters_a_repaint_would_produce(monke
     assert 0 < painted_total < 40 * int(live.sum()), "rasters were repainted %d times for %d live agents" % (painted_total, live.sum())
     skip.close()
     plain.close()
+
+
+@pytest.mark.parametrize("half_angle", [0.0, 3.14159265], ids=["120deg", "360deg"])
+def test_lidar_returns_left_in_place_are_the_returns_a_retrace_would_produce(monkeypatch, half_angle):
+    """k_world_step marks the agents whose LiDAR returns can have changed (own pose or the head angle of the action row changed, or
+    an agent that moved is or was within the rays' reach) and k_lidar traces only those.  Twin simulators on Waymo scenes under the
+    default init rules, one with GPUDRIVE_NO_POSE_SKIP=1 (every live agent traced on every step), same actions -- a few agents
+    drive, some only turn their heads, most stand still -- through a partial reset, a teleport from outside the engine and a
+    set_maps: the same bytes at every step."""
+    kw = dict(PPO_DEFAULT, roadObservationAlgorithm=1, enableLidar=1)
+    scenes = [TEST_JSON, SCENE_407, SCENE_4, SCENE_407]
+    skip = P.make_gpu_sim(scenes, max_agents=128, lidar_half_angle=half_angle, **kw)
+    monkeypatch.setenv("GPUDRIVE_NO_POSE_SKIP", "1")
+    plain = P.make_gpu_sim(scenes, max_agents=128, lidar_half_angle=half_angle, **kw)
+    monkeypatch.delenv("GPUDRIVE_NO_POSE_SKIP")
+    rng = np.random.default_rng(26)
+    traced = 0
+
+    def same(step):
+        a, b = RC.as_np(skip.lidar_tensor()), RC.as_np(plain.lidar_tensor())
+        for w in range(len(scenes)):
+            n = int(RC.as_np(skip.shape_tensor())[w, 0])
+            if not np.array_equal(a[w, :n].view(np.uint32), b[w, :n].view(np.uint32)):
+                bad = np.argwhere(a[w, :n].view(np.uint32) != b[w, :n].view(np.uint32))
+                raise AssertionError("step %d world %d: %d values differ, first at %s" % (step, w, len(bad), bad[0]))
+
+    same(0)
+    for step in range(40):
+        act = P.random_actions(rng, len(scenes), 128, 0)
+        act[:, 3:] = 0.0              # three agents per world drive ...
+        if step % 3 == 0:
+            act[:, 6:9, 2] = rng.uniform(-0.5, 0.5, (len(scenes), 3)).astype(np.float32)   # ... three others turn their heads now and then
+        for s in (skip, plain):
+            RC.write_actions(s, act)
+            s.step()
+        traced += skip.stat(44)
+        if step == 12:
+            for s in (skip, plain):
+                s.reset([0, 3])
+        if step == 20:
+            st = skip.debug_get_state()
+            st[:, 1:3, 0] += 8.0
+            for s in (skip, plain):
+                s.debug_set_state(st)
+                s.reset([])
+        if step == 30:
+            for s in (skip, plain):
+                s.set_maps(scenes[::-1])
+        same(step + 1)
+    live = int(RC.as_np(skip.shape_tensor())[:, 0].sum())
+    assert 0 < traced < 40 * live, "returns were traced %d times for %d live agents over 40 steps" % (traced, live)
+    skip.close()
+    plain.close()

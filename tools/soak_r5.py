@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """developer tool, round 5: the two "leave it where it is" mechanisms at bench size, for hundreds of steps with whole-batch and
 partial resets -- (a) pose stamps: a simulator that skips rows against one that rewrites everything (GPUDRIVE_NO_POSE_SKIP=1),
-agent_roadmap_tensor compared BITWISE; (b) the packed observation written by the step (pack only) against the second pass over
+agent_roadmap_tensor compared BITWISE (mode "bev": the same twin with BEV rasters attached, the rasters compared; mode "lidar": the LiDAR returns); (b) the packed observation written by the step (pack only) against the second pass over
 the raw tensors of a twin simulator, compared bitwise.  gpurun -- python tools/soak_r5.py [steps]   (output kept as
 profiles/r05_soak.txt)"""
 import os, sys, time
@@ -20,7 +20,8 @@ def twin(wl, W, env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        sim = bench.make_sim(bench.scenes_for(name, W, 0, agents), bench.params_for(name), agents, 0, knn_order=order)
+        sim = bench.make_sim(bench.scenes_for(name, W, 0, agents), bench.params_for(name), agents, 0, knn_order=order, enable_bev=(name == "bev"),
+                             lidar_half_angle=float(np.pi) if name == "lidar" else 0.0)
     finally:
         for k, v in old.items():
             if v is None:
@@ -34,7 +35,7 @@ def run(wl, W, mode):
     t0 = time.time()
     with torch.cuda.stream(torch.cuda.Stream(device=dev)):
         a, agents = twin(wl, W, {})
-        b, _ = twin(wl, W, {"GPUDRIVE_NO_POSE_SKIP": "1"} if mode == "skip" else {})
+        b, _ = twin(wl, W, {"GPUDRIVE_NO_POSE_SKIP": "1"} if mode in ("skip", "bev", "lidar") else {})
         if mode == "pack":
             assert a.direct_pack(only=True)
         batches = bench.action_batches(W, agents, dev, seed=77)
@@ -53,7 +54,11 @@ def run(wl, W, mode):
                 for s in (a, b):
                     s.reset(idx)
             if k % 25 == 24 or k == STEPS - 1:
-                if mode == "skip":
+                if mode == "bev":
+                    x, y = a.bev_observation_tensor().to_torch(), b.bev_observation_tensor().to_torch()
+                elif mode == "lidar":
+                    x, y = a.lidar_tensor().to_torch(), b.lidar_tensor().to_torch()
+                elif mode == "skip":
                     x, y = a.agent_roadmap_tensor().to_torch(), b.agent_roadmap_tensor().to_torch()
                 else:
                     x, y = a.packed_observations(), b.packed_observations()
@@ -72,7 +77,7 @@ def run(wl, W, mode):
 total = 0
 for wl, W, mode in (("ppo_default", 1024, "skip"), ("waymo_linear", 1024, "skip"), ("synthetic_linear", 1024, "skip"), ("waymo_set", 1024, "skip"),
                     ("cfg3", 4096, "skip"), ("waymo", 1024, "skip"), ("synthetic_set", 1024, "pack"), ("synthetic", 1024, "pack"),
-                    ("ppo_default", 1024, "pack"), ("waymo_set", 1024, "pack")):
+                    ("ppo_default", 1024, "pack"), ("waymo_set", 1024, "pack"), ("bev", 256, "bev"), ("lidar", 1024, "lidar")):
     total += run(wl, W, mode)
 print("TOTAL different:", total)
 sys.exit(1 if total else 0)
