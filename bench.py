@@ -618,6 +618,7 @@ def main():
                          "prints a line with `distributed` filled in (checks the launch path, e.g. on a CPU-only box with "
                          "--dist-backend gloo)")
     ap.add_argument("--dry-run-sleep", type=float, default=0.0, help="--dry-run only: every rank sleeps this long before it leaves (tests of the launch path's signal handling)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="--dry-run only: this rank leaves with exit code 3 after the ranks were counted (tests of the launch path's exit code, with or without a GPU)")
     ap.add_argument("--headless", action="store_true",
                     help="also print the reference CLI's two lines (src/headless.cpp:145-155) for the primary workload on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -691,6 +692,8 @@ def main():
             gather = dict(ok=bool(ok), rows_per_rank_compact=int(og.cap), controlled_per_rank=[int(c) for c in og.counts.tolist()])
             if args.dry_run_sleep > 0:
                 time.sleep(args.dry_run_sleep)
+        if rank == args.dry_run_fail_rank:
+            raise SystemExit(3)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_counted": int(seen.item()), "gather_round": gather,
                               "gather_bytes_per_rank": gather_bytes_table(args.worlds, args.agents),

@@ -36,6 +36,13 @@ def test_a_failing_rank_fails_the_launch():
     assert "needs an MI355X" in r.stderr
 
 
+def test_a_rank_that_leaves_with_an_error_fails_the_launch_with_or_without_a_gpu():
+    """The exit-code path of the self-launch on any box: in --dry-run nothing touches a GPU, rank 1 leaves with an error after
+    the ranks were counted, and `python bench.py --gpus 2` must not return 0."""
+    r = _run("--gpus", "2", "--dist-backend", "gloo", "--dry-run", "--dry-run-fail-rank", "1")
+    assert r.returncode != 0, r.stdout[-500:]
+
+
 def test_eight_ranks_and_one_gather_round_without_a_launcher():
     """The launch the driver makes on an 8-GPU node, rehearsed with gloo on the CPU box: eight ranks counted, one round of
     config 4's observation gather in both modes with unequal controlled counts, every rank's rows in its own section --
