@@ -2,7 +2,10 @@
 (last row): `GPUDriveTorchEnv.step_dynamics -> get_rewards -> get_dones -> get_obs`
 (reference gpudrive/env/env_torch.py:606-613, 453-505, 897-945), starting from discrete action INDICES that go
 through the action table (`_set_discrete_action_space`, :666-724) and the in-place `[:, :, :3].copy_()` write
-into the exported action tensor (`_copy_actions_to_simulator`, :645-664).
+into the exported action tensor (`_copy_actions_to_simulator`, :645-664); and the calls around an episode:
+`reset` (:403-451), `get_infos` (:462-467), `get_controlled_agents_mask` (:1218-1222), `get_expert_actions`
+(:1445-1509), `advance_sim_with_log_playback` (:1274-1293), `remove_agents_by_id` (:1295-1349), `swap_data_batch`
+(:1351-1384), `get_env_filenames` / `get_scenario_ids` (:1511-1537).
 
 The reference wrapper itself keeps working on top of the drop-in `madrona_gpudrive` module; this class exists
 because it cannot be imported where `gymnasium` / `pufferlib` are missing (the GPU box), and the boundary still
@@ -45,7 +48,7 @@ class TorchCallSequence:
     """`sim` is a `madrona_gpudrive.SimManager`; `dynamics_model` one of "classic", "bicycle", "delta_local", "state"."""
 
     def __init__(self, sim, dynamics_model="classic", reward_type="sparse_on_goal_achieved", norm_obs=True,
-                 action_values=None, vehicle_scale=0.7):
+                 action_values=None, vehicle_scale=0.7, init_steps=0, episode_len=91):
         self.sim = sim
         self.dynamics_model = dynamics_model
         self.reward_type = reward_type
@@ -59,6 +62,10 @@ class TorchCallSequence:
         done = sim.done_tensor().to_torch()
         self.num_worlds, self.max_agent_count = done.shape[0], done.shape[1]
         self.world_time_steps = torch.zeros(self.num_worlds, dtype=torch.short, device=self.device)
+        self.init_steps, self.episode_len = init_steps, episode_len
+        self.data_batch = None
+        if hasattr(sim, "controlled_state_tensor"):
+            self._refresh_masks()
 
     # ---- actions: env_torch.py:666-724, 615-664 ----
     def _set_discrete_action_space(self):
@@ -163,3 +170,111 @@ class TorchCallSequence:
 
     def get_obs(self):
         return torch.cat((self._get_ego_state(), self._get_partner_obs(), self._get_road_map_obs()), dim=-1)
+
+    # ---- around an episode: env_torch.py:403-451, 462-467, 1218-1222 ----
+    def _refresh_masks(self):
+        self.cont_agent_mask = self.get_controlled_agents_mask()
+        self.max_agent_count = self.cont_agent_mask.shape[1]
+        self.num_valid_controlled_agents_across_worlds = self.cont_agent_mask.sum().item()
+
+    def get_controlled_agents_mask(self):
+        return (self.sim.controlled_state_tensor().to_torch().clone() == 1).squeeze(axis=2)
+
+    def reset(self, mask=None, env_idx_list=None):
+        """All worlds (or `env_idx_list`) back to their first step, the clock of every world to zero, the logged warm-up if
+        `init_steps` was given; returns the observations (of the agents in `mask`, if given)."""
+        if env_idx_list is None:
+            env_idx_list = list(range(self.num_worlds))
+        self.sim.reset(env_idx_list)
+        self.world_time_steps.zero_()
+        if self.init_steps > 0:
+            self.advance_sim_with_log_playback(init_steps=self.init_steps)
+        obs = self.get_obs()
+        return obs if mask is None else obs[mask]
+
+    class Info:
+        """gpudrive/datatypes/info.py:11-15: off_road = column 0, collided = columns 1 + 2, goal_achieved = column 3."""
+
+        def __init__(self, info):
+            self.off_road = info[:, :, 0]
+            self.collided = info[:, :, 1:3].sum(axis=2)
+            self.goal_achieved = info[:, :, 3]
+
+        @property
+        def shape(self):
+            return self.off_road.shape
+
+    def get_infos(self):
+        return TorchCallSequence.Info(self.sim.info_tensor().to_torch().clone().to(self.device))
+
+    # ---- the logged trajectories: env_torch.py:1445-1509, gpudrive/datatypes/trajectory.py:21-40 ----
+    def get_expert_actions(self):
+        """(inferred_actions, pos_xy, vel_xy, yaw, valids) over the 91 logged steps: the expert rows are 2 x 91 positions,
+        2 x 91 velocities, 91 headings, 91 valid flags and 91 x 10 inferred action columns per agent slot; the inferred actions
+        are clamped per dynamics model (classic / bicycle: acceleration +-6, steering +-0.3; delta_local: +-6, +-6, +-pi),
+        `state` takes (x, y, 1, yaw, vx, vy, 0, 0, 0, 0) instead."""
+        T = 91
+        raw = self.sim.expert_trajectory_tensor().to_torch().clone()
+        W, A = self.num_worlds, raw.shape[1]
+        pos_xy = raw[:, :, :2 * T].view(W, A, T, -1)
+        vel_xy = raw[:, :, 2 * T:4 * T].view(W, A, T, -1)
+        yaw = raw[:, :, 4 * T:5 * T].view(W, A, T, -1)
+        valids = raw[:, :, 5 * T:6 * T].view(W, A, T, -1).to(torch.int32)
+        inferred = raw[:, :, 6 * T:16 * T].view(W, A, T, -1)
+        if self.dynamics_model == "delta_local":
+            act = inferred[..., :3]
+            act[..., 0] = torch.clamp(act[..., 0], -6, 6)
+            act[..., 1] = torch.clamp(act[..., 1], -6, 6)
+            act[..., 2] = torch.clamp(act[..., 2], -torch.pi, torch.pi)
+        elif self.dynamics_model == "state":
+            ones = torch.ones((*pos_xy.shape[:-1], 1), device=raw.device)
+            zeros = torch.zeros((*pos_xy.shape[:-1], 4), device=raw.device)
+            act = torch.cat((pos_xy, ones, yaw, vel_xy, zeros), dim=-1)
+        else:
+            act = inferred[..., :3]
+            act[..., 0] = torch.clamp(act[..., 0], -6, 6)
+            act[..., 1] = torch.clamp(act[..., 1], -0.3, 0.3)
+        return act, pos_xy, vel_xy, yaw, valids
+
+    def advance_sim_with_log_playback(self, init_steps=0):
+        if init_steps >= self.episode_len:
+            raise ValueError("The length of the expert trajectory is 91,"
+                             f"so init_steps = {init_steps} should be < than 91.")
+        self.log_playback_traj, _, _, _, _ = self.get_expert_actions()
+        for time_step in range(init_steps):
+            self.step_dynamics(actions=self.log_playback_traj[:, :, time_step, :])
+
+    # ---- the scenes under the worlds: env_torch.py:1295-1384, 1511-1537 ----
+    def remove_agents_by_id(self, perc_to_rmv_per_scene, remove_controlled_agents=True, generator=None):
+        """Deletes a share of every world's (controlled, or uncontrolled) agents by their ids through `sim.deleteAgents`, at
+        least one per world that has any, then re-reads the controlled mask."""
+        if perc_to_rmv_per_scene <= 0.0:
+            return
+        agent_ids = self.sim.self_observation_tensor().to_torch().clone()[:, :, 7]
+        agent_mask = self.cont_agent_mask if remove_controlled_agents else (~self.cont_agent_mask) & (agent_ids != -1)
+        for env_idx in range(self.num_worlds):
+            scene_agent_ids = agent_ids[env_idx, :][agent_mask[env_idx]].long()
+            if scene_agent_ids.numel() > 0:
+                num_to_sample = max(1, int(perc_to_rmv_per_scene * scene_agent_ids.size(0)))
+                sampled = scene_agent_ids[torch.randperm(scene_agent_ids.size(0), generator=generator)[:num_to_sample]]
+                self.sim.deleteAgents({env_idx: sampled.tolist()})
+        self._refresh_masks()
+
+    def swap_data_batch(self, data_batch):
+        """New scenes under every world (`sim.set_maps`), the controlled mask re-read."""
+        if len(data_batch) != self.num_worlds:
+            raise ValueError(f"Data batch size ({len(data_batch)}) does not match "
+                             f"the expected number of worlds ({self.num_worlds}).")
+        self.data_batch = data_batch
+        self.sim.set_maps(self.data_batch)
+        self._refresh_masks()
+
+    def _names(self, tensor):
+        ints = tensor.to_torch()
+        return {i: "".join(chr(c) for c in ints[i].tolist() if c != 0) for i in range(self.num_worlds)}
+
+    def get_env_filenames(self):
+        return self._names(self.sim.map_name_tensor())
+
+    def get_scenario_ids(self):
+        return self._names(self.sim.scenario_id_tensor())

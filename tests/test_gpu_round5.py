@@ -3,6 +3,8 @@ gpudrive/env/config.py:51 -> src/sim.cpp:258-279) in its own kernel (csrc/map_ob
 scenes bench.py times and at BASELINE.json's full size, against the kernels that carried the mode in rounds 1-4, and the rule
 that rows which cannot have changed are not rewritten (pose stamps) through resets, map changes and agent deletions.
 Everything goes through `madrona_gpudrive` -> ctypes -> the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -546,3 +548,48 @@ def test_lidar_returns_left_in_place_are_the_returns_a_retrace_would_produce(mon
     assert 0 < traced < 40 * live, "returns were traced %d times for %d live agents over 40 steps" % (traced, live)
     skip.close()
     plain.close()
+
+
+def test_gym_wrapper_episode_calls_on_the_device(oracle_mod):
+    """The calls GPUDriveTorchEnv makes around an episode, through gpudrive_lab_amd/harness.py on the real module: the expert
+    actions sliced from the exported trajectory equal the kernel's (`sim.expert_actions()`), a reset with warm-up steps leaves
+    the simulator where the device-side log playback leaves a twin, infos / controlled mask / file names read what the oracle
+    holds, `remove_agents_by_id` and `swap_data_batch` go through deleteAgents / set_maps and re-read the mask."""
+    import torch
+    from gpudrive_lab_amd.harness import TorchCallSequence
+    scenes = [SCENE_4, SCENE_407, TEST_JSON]
+    kw = dict(polylineReductionThreshold=0.1, observationRadius=50.0, collisionBehaviour=0, rewardType=1, distanceToGoalThreshold=2.0,
+              dynamicsModel=0, **ALL_OBJECTS)
+    gpu = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    twin = P.make_gpu_sim(scenes, max_agents=64, **kw)
+    orc = P.make_oracle_sim(oracle_mod, scenes, max_agents=64, **kw)
+    env = TorchCallSequence(gpu, dynamics_model="classic", init_steps=4)
+    for a, b in zip(env.get_expert_actions(), gpu.expert_actions()):
+        assert a.shape == b.shape and torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
+                                                  b.view(torch.int32) if b.dtype == torch.float32 else b)
+    obs = env.reset()
+    twin.reset(list(range(3)))
+    twin.advance_log_playback(4)
+    for name in ("self_observation_tensor", "partner_observations_tensor", "agent_roadmap_tensor", "done_tensor", "info_tensor",
+                 "steps_remaining_tensor"):
+        x, y = RC.as_np(getattr(gpu, name)()), RC.as_np(getattr(twin, name)())
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y), name
+    assert torch.allclose(obs, twin.packed_observations(), atol=3e-7, rtol=1e-6)
+    ctrl = np.asarray(orc.controlled_state_tensor())[..., 0] == 1
+    assert np.array_equal(env.get_controlled_agents_mask().cpu().numpy(), ctrl)
+    assert env.num_valid_controlled_agents_across_worlds == int(ctrl.sum())
+    names = env.get_env_filenames()   # (the scene's own "name" field, src/MapReader.cpp -> map_name_tensor)
+    exp_names = ["".join(chr(c) for c in row if c != 0) for row in np.asarray(orc.map_name_tensor()).tolist()]
+    assert [names[w] for w in range(3)] == exp_names and all(n.endswith(".json") for n in exp_names)
+    info = env.get_infos()
+    assert info.shape == (3, 64) and np.array_equal(info.goal_achieved.cpu().numpy(), RC.as_np(gpu.info_tensor())[..., 3])
+    before = int(RC.as_np(gpu.shape_tensor())[:, 0].sum())
+    env.remove_agents_by_id(0.25, remove_controlled_agents=True, generator=torch.Generator().manual_seed(4))
+    after = int(RC.as_np(gpu.shape_tensor())[:, 0].sum())
+    assert after < before and env.num_valid_controlled_agents_across_worlds < int(ctrl.sum())
+    env.swap_data_batch(scenes[::-1])
+    orc.set_maps(scenes[::-1])
+    assert np.array_equal(env.get_controlled_agents_mask().cpu().numpy(), np.asarray(orc.controlled_state_tensor())[..., 0] == 1)
+    P.compare_fresh(gpu, orc)
+    gpu.close()
+    twin.close()

@@ -25,10 +25,28 @@ class FakeSim:
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt)
         self.t = dict(action=z(W, A, 10), done=z(W, A, 1, dt=torch.int32), info=z(W, A, 5, dt=torch.int32), reward=z(W, A, 1),
                       self_obs=z(W, A, 8), partner=z(W, A, A - 1, 9), roadmap=z(W, A, 200, 9))
+        self.t.update(controlled=z(W, A, 1, dt=torch.int32), traj=z(W, A, 16 * 91), map_name=z(W, 32, dt=torch.int32),
+                      scenario=z(W, 32, dt=torch.int32))
         self.steps = 0
+        self.calls = []
 
     def step(self):
         self.steps += 1
+        self.calls.append(("step", self.t["action"][:, :, :3].clone()))
+
+    def reset(self, worlds):
+        self.calls.append(("reset", list(worlds)))
+
+    def set_maps(self, maps):
+        self.calls.append(("set_maps", list(maps)))
+
+    def deleteAgents(self, d):
+        self.calls.append(("deleteAgents", dict(d)))
+
+    controlled_state_tensor = lambda self: _T(self.t["controlled"])
+    expert_trajectory_tensor = lambda self: _T(self.t["traj"])
+    map_name_tensor = lambda self: _T(self.t["map_name"])
+    scenario_id_tensor = lambda self: _T(self.t["scenario"])
 
     action_tensor = lambda self: _T(self.t["action"])
     done_tensor = lambda self: _T(self.t["done"])
@@ -97,3 +115,114 @@ def test_rewards_and_dones_follow_the_wrapper():
     assert TorchCallSequence(sim).get_rewards()[0, 1].item() == 1.0
     d = h.get_dones()
     assert d.dtype == torch.float32 and d[0, 1].item() == 1.0 and d.sum().item() == 1.0
+
+
+def _fill_traj(sim, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    sim.t["traj"].copy_(torch.rand(sim.t["traj"].shape, generator=g) * 20 - 10)
+    sim.t["traj"][:, :, 5 * 91:6 * 91] = (torch.rand(sim.t["traj"][:, :, 5 * 91:6 * 91].shape, generator=g) < 0.7).float()
+
+
+def test_expert_actions_follow_the_trajectory_layout_and_the_clamps():
+    """gpudrive/datatypes/trajectory.py:21-40 + env_torch.py:1445-1509, restated independently with numpy strides."""
+    sim = FakeSim(W=2, A=64)
+    _fill_traj(sim)
+    raw = sim.t["traj"].numpy().copy()
+    T = 91
+    inferred = raw[:, :, 6 * T:].reshape(2, 64, T, 10)
+    for model in ("classic", "delta_local", "state"):
+        act, pos, vel, yaw, valid = TorchCallSequence(sim, dynamics_model=model).get_expert_actions()
+        assert np.array_equal(pos.numpy(), raw[:, :, :2 * T].reshape(2, 64, T, 2))
+        assert np.array_equal(vel.numpy(), raw[:, :, 2 * T:4 * T].reshape(2, 64, T, 2))
+        assert np.array_equal(yaw.numpy(), raw[:, :, 4 * T:5 * T].reshape(2, 64, T, 1))
+        assert valid.dtype == torch.int32 and np.array_equal(valid.numpy(), raw[:, :, 5 * T:6 * T].reshape(2, 64, T, 1).astype(np.int32))
+        if model == "classic":
+            exp = inferred[..., :3].copy()
+            exp[..., 0] = np.clip(exp[..., 0], -6, 6); exp[..., 1] = np.clip(exp[..., 1], -0.3, 0.3)
+        elif model == "delta_local":
+            exp = inferred[..., :3].copy()
+            exp[..., 0] = np.clip(exp[..., 0], -6, 6); exp[..., 1] = np.clip(exp[..., 1], -6, 6)
+            exp[..., 2] = np.clip(exp[..., 2], -np.float32(np.pi), np.float32(np.pi))
+        else:
+            exp = np.concatenate([pos.numpy(), np.ones((2, 64, T, 1), np.float32), yaw.numpy(), vel.numpy(),
+                                  np.zeros((2, 64, T, 4), np.float32)], axis=-1)
+        assert act.shape == exp.shape and np.array_equal(act.numpy(), exp), model
+    assert np.array_equal(sim.t["traj"].numpy(), raw), "the exported tensor must not be clamped in place"
+
+
+def test_reset_zeroes_the_clocks_and_plays_the_log_for_the_warm_up_steps():
+    sim = FakeSim(W=2, A=64)
+    _fill_traj(sim)
+    h = TorchCallSequence(sim, dynamics_model="classic", init_steps=3)
+    h.world_time_steps += 7
+    obs = h.reset()
+    assert obs.shape == (2, 64, 6 + 63 * 6 + 200 * 13)
+    assert sim.calls[0] == ("reset", [0, 1])
+    steps = [c for c in sim.calls if c[0] == "step"]
+    assert len(steps) == 3 and (h.world_time_steps == 3).all()   # (zeroed, then three logged steps)
+    exp = h.get_expert_actions()[0]
+    for k in range(3):
+        assert torch.equal(steps[k][1], exp[:, :, k, :])
+    sim.calls.clear()
+    mask = torch.zeros(2, 64, dtype=torch.bool)
+    mask[1, :5] = True
+    assert TorchCallSequence(sim).reset(mask=mask, env_idx_list=[1]).shape == (5, 6 + 63 * 6 + 200 * 13)
+    assert sim.calls[0] == ("reset", [1])
+    try:
+        h.advance_sim_with_log_playback(init_steps=91)
+        raise AssertionError("init_steps = 91 must be refused")
+    except ValueError:
+        pass
+
+
+def test_infos_masks_names_and_scene_changes():
+    sim = FakeSim(W=2, A=64)
+    sim.t["info"][0, 0] = torch.tensor([1, 1, 1, 0, 7], dtype=torch.int32)
+    sim.t["info"][1, 3] = torch.tensor([0, 0, 0, 1, 7], dtype=torch.int32)
+    sim.t["controlled"][0, :4, 0] = 1
+    sim.t["controlled"][1, 2:5, 0] = 1
+    sim.t["self_obs"][:, :, 7] = -1
+    sim.t["self_obs"][0, :6, 7] = torch.arange(100, 106).float()
+    sim.t["self_obs"][1, :6, 7] = torch.arange(200, 206).float()
+    for w, name in enumerate(("tfrecord-00001.json", "x.json")):
+        sim.t["map_name"][w, :len(name)] = torch.tensor([ord(c) for c in name], dtype=torch.int32)
+        sim.t["scenario"][w, :3] = torch.tensor([ord(c) for c in "ab%d" % w], dtype=torch.int32)
+    h = TorchCallSequence(sim)
+    info = h.get_infos()
+    assert info.shape == (2, 64) and info.off_road[0, 0] == 1 and info.collided[0, 0] == 2 and info.goal_achieved[1, 3] == 1
+    m = h.get_controlled_agents_mask()
+    assert m.dtype == torch.bool and m.shape == (2, 64) and m.sum().item() == 7 and h.num_valid_controlled_agents_across_worlds == 7
+    assert h.get_env_filenames() == {0: "tfrecord-00001.json", 1: "x.json"} and h.get_scenario_ids() == {0: "ab0", 1: "ab1"}
+    # half of the controlled agents of every world, by id, at least one
+    h.remove_agents_by_id(0.5, remove_controlled_agents=True, generator=torch.Generator().manual_seed(1))
+    dels = [c[1] for c in sim.calls if c[0] == "deleteAgents"]
+    assert len(dels) == 2 and len(dels[0][0]) == 2 and len(dels[1][1]) == 1
+    assert set(dels[0][0]) <= {100, 101, 102, 103} and set(dels[1][1]) <= {202, 203, 204}
+    sim.calls.clear()
+    h.remove_agents_by_id(0.34, remove_controlled_agents=False, generator=torch.Generator().manual_seed(2))
+    dels = [c[1] for c in sim.calls if c[0] == "deleteAgents"]
+    assert set(dels[0][0]) <= {104, 105} and set(dels[1][1]) <= {200, 201, 205}   # uncontrolled agents with an id
+    h.remove_agents_by_id(0.0)
+    sim.calls.clear()
+    try:
+        h.swap_data_batch(["a.json"])
+        raise AssertionError("a batch of the wrong size must be refused")
+    except ValueError:
+        pass
+    sim.t["controlled"][0, :4, 0] = 0
+    h.swap_data_batch(["a.json", "b.json"])
+    assert sim.calls == [("set_maps", ["a.json", "b.json"])] and h.num_valid_controlled_agents_across_worlds == 3
+
+
+def test_expert_actions_match_the_reference_datatypes_golden():
+    """tests/golden/expert_actions_golden.npz was produced by the reference's own LogTrajectory class and the wrapper's
+    clamps (make_expert_actions_golden.py): the harness's restatement gives the same bits."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "expert_actions_golden.npz"))
+    n = g["raw"].shape[1]
+    sim = FakeSim(W=1, A=64)
+    sim.t["traj"][0, :n] = torch.from_numpy(g["raw"][0])
+    for model in ("classic", "delta_local", "state"):
+        act, pos, vel, yaw, valid = TorchCallSequence(sim, dynamics_model=model).get_expert_actions()
+        assert np.array_equal(act[:, :n].numpy().view(np.uint32), g[model + "_actions"].view(np.uint32)), model
+        assert np.array_equal(pos[:, :n].numpy(), g["pos_xy"]) and np.array_equal(vel[:, :n].numpy(), g["vel_xy"])
+        assert np.array_equal(yaw[:, :n].numpy(), g["yaw"]) and np.array_equal(valid[:, :n].numpy(), g["valids"])
