@@ -5,7 +5,8 @@ through the action table (`_set_discrete_action_space`, :666-724) and the in-pla
 into the exported action tensor (`_copy_actions_to_simulator`, :645-664); and the calls around an episode:
 `reset` (:403-451), `get_infos` (:462-467), `get_controlled_agents_mask` (:1218-1222), `get_expert_actions`
 (:1445-1509), `advance_sim_with_log_playback` (:1274-1293), `remove_agents_by_id` (:1295-1349), `swap_data_batch`
-(:1351-1384), `get_env_filenames` / `get_scenario_ids` (:1511-1537).
+(:1351-1384), `get_env_filenames` / `get_scenario_ids` (:1511-1537), the partner / road masks (:1224-1272), the optional
+LiDAR and BEV observations (:898-945) and frame stacking (:1209-1216).
 
 The reference wrapper itself keeps working on top of the drop-in `madrona_gpudrive` module; this class exists
 because it cannot be imported where `gymnasium` / `pufferlib` are missing (the GPU box), and the boundary still
@@ -38,6 +39,7 @@ MIN_RG_COORD, MAX_RG_COORD = -1000, 1000
 MAX_ROAD_LINE_SEGMENT_LEN = 100
 MAX_ROAD_SCALE = 100
 ROAD_TYPES = 7
+NUM_MADRONA_ENTITY_TYPES = 11  # gpudrive/env/constants.py:32
 
 
 def _normalize_min_max(x, lo, hi):  # gpudrive/utils/geometry.py normalize_min_max
@@ -48,7 +50,7 @@ class TorchCallSequence:
     """`sim` is a `madrona_gpudrive.SimManager`; `dynamics_model` one of "classic", "bicycle", "delta_local", "state"."""
 
     def __init__(self, sim, dynamics_model="classic", reward_type="sparse_on_goal_achieved", norm_obs=True,
-                 action_values=None, vehicle_scale=0.7, init_steps=0, episode_len=91):
+                 action_values=None, vehicle_scale=0.7, init_steps=0, episode_len=91, num_stack=1):
         self.sim = sim
         self.dynamics_model = dynamics_model
         self.reward_type = reward_type
@@ -62,7 +64,8 @@ class TorchCallSequence:
         done = sim.done_tensor().to_torch()
         self.num_worlds, self.max_agent_count = done.shape[0], done.shape[1]
         self.world_time_steps = torch.zeros(self.num_worlds, dtype=torch.short, device=self.device)
-        self.init_steps, self.episode_len = init_steps, episode_len
+        self.init_steps, self.episode_len, self.num_stack = init_steps, episode_len, num_stack
+        self.stacked_obs = None
         self.data_batch = None
         if hasattr(sim, "controlled_state_tensor"):
             self._refresh_masks()
@@ -168,8 +171,55 @@ class TorchCallSequence:
         return torch.cat([x.unsqueeze(-1), y.unsqueeze(-1), seg_len.unsqueeze(-1), seg_w.unsqueeze(-1),
                           seg_h.unsqueeze(-1), yaw.unsqueeze(-1), types], dim=-1).flatten(start_dim=2)
 
-    def get_obs(self):
-        return torch.cat((self._get_ego_state(), self._get_partner_obs(), self._get_road_map_obs()), dim=-1)
+    def get_obs(self, mask=None, reset=False):
+        """env_torch.py:1172-1216: ego | partners | roads per agent slot, the last `num_stack` frames side by side (zeros for the
+        frames before a reset), and the partner mask of the frame kept for `get_partner_mask`."""
+        partner = self._get_partner_obs()
+        obs = torch.cat((self._get_ego_state(), partner, self._get_road_map_obs()), dim=-1)
+        if hasattr(self.sim, "response_type_tensor"):
+            self.partner_mask = self.make_partner_mask(partner)
+        if self.num_stack > 1:
+            if reset or self.stacked_obs is None:
+                prev = torch.zeros_like(obs).repeat(1, 1, self.num_stack - 1)
+            else:
+                prev = self.stacked_obs[..., obs.shape[-1]:]
+            self.stacked_obs = torch.cat([prev, obs], dim=-1)
+            obs = self.stacked_obs.clone()
+        return obs if mask is None else obs[mask]
+
+    # ---- masks and the optional sensors: env_torch.py:1224-1272, 898-945 ----
+    def make_partner_mask(self, partner_observations):
+        """Per ego and partner slot: 0 a partner that acts, 1 a `Static` one with a non-zero row, 2 nobody (id <= -1).  (The
+        reference writes this fork's 127 partner slots as a literal; here it is max_agent_count - 1.)"""
+        B, A, _ = partner_observations.shape
+        partner_sum = partner_observations.reshape(B, A, A - 1, 6).sum(-1)
+        static_mask = (self.sim.response_type_tensor().to_torch().clone().to(self.device) == 2).squeeze(-1)
+        eye_mask = ~torch.eye(A, dtype=torch.bool)
+        relative_static_mask = static_mask.unsqueeze(1).expand(-1, A, -1)[:, eye_mask].reshape(B, A, -1)
+        filtered_static_mask = relative_static_mask & (partner_sum != 0)
+        partner_ids = self.sim.partner_observations_tensor().to_torch().clone().to(self.device)[..., 8]
+        return torch.where(filtered_static_mask, 1, torch.where(partner_ids <= -1, 2, 0))
+
+    def get_partner_mask(self):
+        return self.partner_mask.clone()
+
+    def get_road_mask(self):
+        """True where a road row is padding (id -1)."""
+        return self.sim.agent_roadmap_tensor().to_torch().clone().to(self.device)[..., 7] == -1
+
+    def _get_lidar_obs(self, mask=None):
+        """[W, A, 3 planes, rays, 4] -> agent | road-edge | road-line samples side by side per agent."""
+        lidar = self.sim.lidar_tensor().to_torch().clone().to(self.device)
+        planes = [lidar[:, :, 0, :, :], lidar[:, :, 1, :, :], lidar[:, :, 2, :, :]]
+        if mask is not None:
+            return [p[mask] for p in planes]
+        return torch.cat(planes, dim=-1).flatten(start_dim=2)
+
+    def _get_bev_obs(self, mask=None):
+        """The 200 x 200 entity-type raster, one-hot over Madrona's 11 entity types."""
+        bev = torch.nn.functional.one_hot(self.sim.bev_observation_tensor().to_torch().clone().to(self.device).long(),
+                                          num_classes=NUM_MADRONA_ENTITY_TYPES)
+        return bev[mask].flatten(start_dim=1) if mask is not None else bev.flatten(start_dim=2)
 
     # ---- around an episode: env_torch.py:403-451, 462-467, 1218-1222 ----
     def _refresh_masks(self):
@@ -189,8 +239,7 @@ class TorchCallSequence:
         self.world_time_steps.zero_()
         if self.init_steps > 0:
             self.advance_sim_with_log_playback(init_steps=self.init_steps)
-        obs = self.get_obs()
-        return obs if mask is None else obs[mask]
+        return self.get_obs(mask, reset=True)
 
     class Info:
         """gpudrive/datatypes/info.py:11-15: off_road = column 0, collided = columns 1 + 2, goal_achieved = column 3."""

@@ -27,6 +27,7 @@ class FakeSim:
                       self_obs=z(W, A, 8), partner=z(W, A, A - 1, 9), roadmap=z(W, A, 200, 9))
         self.t.update(controlled=z(W, A, 1, dt=torch.int32), traj=z(W, A, 16 * 91), map_name=z(W, 32, dt=torch.int32),
                       scenario=z(W, 32, dt=torch.int32))
+        self.t.update(resp=z(W, A, 1, dt=torch.int32), lidar=z(W, A, 3, 30, 4), bev=z(W, A, 8, 8, 1))
         self.steps = 0
         self.calls = []
 
@@ -43,6 +44,9 @@ class FakeSim:
     def deleteAgents(self, d):
         self.calls.append(("deleteAgents", dict(d)))
 
+    response_type_tensor = lambda self: _T(self.t["resp"])
+    lidar_tensor = lambda self: _T(self.t["lidar"])
+    bev_observation_tensor = lambda self: _T(self.t["bev"])
     controlled_state_tensor = lambda self: _T(self.t["controlled"])
     expert_trajectory_tensor = lambda self: _T(self.t["traj"])
     map_name_tensor = lambda self: _T(self.t["map_name"])
@@ -226,3 +230,40 @@ def test_expert_actions_match_the_reference_datatypes_golden():
         assert np.array_equal(act[:, :n].numpy().view(np.uint32), g[model + "_actions"].view(np.uint32)), model
         assert np.array_equal(pos[:, :n].numpy(), g["pos_xy"]) and np.array_equal(vel[:, :n].numpy(), g["vel_xy"])
         assert np.array_equal(yaw[:, :n].numpy(), g["yaw"]) and np.array_equal(valid[:, :n].numpy(), g["valids"])
+
+
+def test_masks_sensors_and_frame_stacking():
+    sim = FakeSim(W=1, A=64)
+    sim.t["partner"][..., 8] = -2            # nobody anywhere ...
+    sim.t["partner"][0, 0, 0] = torch.tensor([3.0, 1.0, 2.0, 0.1, 4.5, 2.0, 1.5, 1.0, 11.0])   # ... but ego 0 sees agent 1 (slot 0)
+    sim.t["partner"][0, 0, 1] = torch.tensor([0.0, 5.0, 6.0, 0.2, 4.5, 2.0, 1.5, 1.0, 12.0])   # ... and the parked agent 2 (slot 1)
+    sim.t["partner"][0, 2, 0] = torch.tensor([3.0, -5.0, -6.0, 0.0, 4.5, 2.0, 1.5, 1.0, 10.0])  # ego 2 sees agent 0
+    sim.t["resp"][0, 2, 0] = 2               # agent 2 is Static
+    sim.t["resp"][0, 3:, 0] = 2              # padding slots are Static too, with all-zero rows
+    sim.t["roadmap"][..., 7] = -1
+    sim.t["roadmap"][0, 0, :5, 7] = torch.arange(5).float()
+    h = TorchCallSequence(sim, num_stack=3)
+    first = h.get_obs(reset=True)
+    D = 6 + 63 * 6 + 200 * 13
+    assert first.shape == (1, 64, 3 * D) and (first[..., :2 * D] == 0).all()
+    m = h.get_partner_mask()
+    assert m.shape == (1, 64, 63)
+    assert m[0, 0, 0] == 0 and m[0, 0, 1] == 1 and m[0, 0, 2] == 2      # acting partner, parked partner, nobody
+    assert m[0, 2, 0] == 0 and (m[0, 1] == 2).all()
+    rm = h.get_road_mask()
+    assert rm.shape == (1, 64, 200) and rm[0, 0, :5].sum() == 0 and rm[0, 0, 5:].all() and rm[0, 1].all()
+    sim.t["self_obs"][0, 0, 0] = 50.0        # the next frame differs
+    second = h.get_obs()
+    assert torch.equal(second[..., D:2 * D], first[..., 2 * D:]) and (second[..., :D] == 0).all()
+    assert second[0, 0, 2 * D].item() == 0.5 and first[0, 0, 2 * D].item() == 0.0
+    assert h.get_obs(reset=True)[..., :2 * D].abs().sum() == 0              # a reset forgets the earlier frames
+    # LiDAR: the three planes side by side per ray; BEV: one-hot over the 11 entity types
+    sim.t["lidar"][0, 0] = torch.arange(3 * 30 * 4).float().view(3, 30, 4)
+    lo = h._get_lidar_obs()
+    assert lo.shape == (1, 64, 30 * 12)
+    assert torch.equal(lo[0, 0].view(30, 12)[:, 4:8], sim.t["lidar"][0, 0, 1])
+    parts = h._get_lidar_obs(mask=torch.tensor([[True] + [False] * 63]))
+    assert len(parts) == 3 and parts[2].shape == (1, 30, 4)
+    sim.t["bev"][0, 0, 2, 3, 0] = 7.0
+    bo = h._get_bev_obs()
+    assert bo.shape == (1, 64, 8 * 8 * 11) and bo[0, 0].view(8, 8, 11)[2, 3, 7] == 1 and bo[0, 0].view(8, 8, 11)[0, 0, 0] == 1
